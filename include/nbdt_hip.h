@@ -1,0 +1,194 @@
+/*
+ * nbdt_hip.h -- C-ABI of libnbdt_hip.so, the MI355X (gfx950) native hot path of
+ * Neural-Backed Decision Trees.
+ *
+ * The reference (alvinwan/neural-backed-decision-trees) is 100% Python and has no
+ * FFI/plugin registry: its boundary for this path is the nn.Module API
+ *   nbdt/model.py:65-273   EmbeddedDecisionRules / Hard* / Soft*   (rules layer)
+ *   nbdt/loss.py:97-266    TreeSupLoss / SoftTreeSupLoss           (tree-supervision loss)
+ *   nbdt/models/resnet.py:42-149, nbdt/models/wideresnet.py:1-40   (backbones; every op a
+ *                          stock aten/cuDNN kernel: Conv2d, BatchNorm2d, ReLU, avg-pool, Linear)
+ *   main.py:207,233-239    SGD(momentum .9, wd 5e-4) train step
+ * Each entry point below replaces the stock-op sequence named in its comment.  The host side
+ * (neural-backed-decision-trees_amd/nbdt, Python, same class names/signatures as the
+ * reference) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer borrowed for the duration
+ *     of the stream-ordered call unless marked "host"; the caller (PyTorch caching allocator)
+ *     owns all tensors.  The library owns only tree handles.
+ *   - every call returns 0 on success, a negative NBDT_E* code on failure and never throws;
+ *     nbdt_last_error() returns a thread-local message for the last failure.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous and re-entrant across streams/devices.
+ *   - activations are "padded NHWC bf16": [B][H+2][W+2][C] with a zero one-pixel border
+ *     (so every 3x3 tap is in-bounds); kernels write interiors only.
+ *   - conv weights are [Cout][taps][Cin] bf16 ("KRSC"), fp32 masters in the same order.
+ */
+#ifndef NBDT_HIP_H
+#define NBDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBDT_OK 0
+#define NBDT_EINVAL (-1)   /* bad argument / unsupported shape */
+#define NBDT_EHIP (-2)     /* HIP runtime error */
+#define NBDT_ENOMEM (-3)
+
+/* element types of the logits handed to the rules layer */
+#define NBDT_F32 0
+#define NBDT_BF16 1
+#define NBDT_F16 2
+
+const char* nbdt_last_error(void);
+int nbdt_version(void);
+/* number of visible HIP devices (0 => the product path must refuse to run) */
+int nbdt_device_count(void);
+
+/* ------------------------------------------------------------------ hierarchy handle
+ * Flattened form of nbdt/tree.py Tree/Node (build_class_mappings :105-125):
+ *   N inner nodes in `tree.inodes` order (sorted wnid), node n owns child slots
+ *   [node_off[n], node_off[n+1]);  slot s averages the logits of classes
+ *   slot_cls[slot_off[s] .. slot_off[s+1]) (ascending);  class c lies under slots
+ *   cls_slot[cls_off[c] .. cls_off[c+1]) (inode order);  slot_next[s] = inode index of the
+ *   child if it is an inner node, else -(class_index)-1.   All arrays are HOST pointers and are
+ *   copied to `device`. */
+typedef struct nbdt_tree nbdt_tree;
+int nbdt_tree_create(int device, int num_classes, int num_inodes, int root,
+                     const int32_t* node_off, const int32_t* slot_off, const int32_t* slot_cls,
+                     const int32_t* cls_off, const int32_t* cls_slot, const int32_t* slot_next,
+                     nbdt_tree** out);
+int nbdt_tree_destroy(nbdt_tree* t);
+int nbdt_tree_max_depth(const nbdt_tree* t);
+
+/* ------------------------------------------------------------------ rules layer
+ * z: [B, C] logits, row stride ldz elements, element type ztype.  Outputs are fp32/int64,
+ * dense row-major. */
+
+/* SoftEmbeddedDecisionRules.forward (nbdt/model.py:207-242, 268-273): P[B,C] path probabilities */
+int nbdt_soft_forward(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                      float* P, void* stream);
+/* autograd of the above: gz[B,C] (fp32) = d<gP,P>/dz ; recomputes the forward from z */
+int nbdt_soft_backward(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                       const float* gP, float* gz, void* stream);
+/* SoftTreeSupLoss.forward + backward fused (nbdt/loss.py:191-203, 260-266) for
+ * criterion = nn.CrossEntropyLoss():  loss = w_x*CE(z,y) + w_t*CE(P,y) (mean over B),
+ * gz = grad_scale * dloss/dz.  row_loss: [B] fp32 scratch; loss: 1 fp32. */
+int nbdt_soft_tree_loss(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                        const int64_t* y, float w_xent, float w_tree, float grad_scale,
+                        float* row_loss, float* loss, float* gz, void* stream);
+/* HardEmbeddedDecisionRules.forward_with_decisions (nbdt/model.py:145-199): pred[B] int64,
+ * optional onehot[B,C] fp32 (predicted_to_logits), optional decision buffers
+ * [B, max_depth]: inode index / chosen child / its prob / node entropy (-1 padded). */
+int nbdt_hard_forward(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                      int64_t* pred, float* onehot, int32_t* path_node, int32_t* path_child,
+                      float* path_prob, float* path_entropy, void* stream);
+/* EmbeddedDecisionRules.forward_nodes (nbdt/model.py:101-123): per-slot logits/probs [B,R],
+ * per-node preds [B,N] int64 and entropy [B,N]; any output may be NULL. */
+int nbdt_node_outputs(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                      float* logits, float* probs, int64_t* preds, float* entropy, void* stream);
+
+/* ------------------------------------------------------------------ backbone: implicit-GEMM conv
+ * One launch = one "tap table": out[pix(m)][n] (+)= sum_t sum_c in[pix_in(m) + tap_off[t]][c] *
+ * w[n][w_tap[t]][c].  Pixel m of the launch's M-pixel grid decomposes as (b, i, j) over
+ * (B, gh, gw); element offsets are affine: b*bs + i*hs + j*ws + base.  This single kernel is
+ * Conv2d forward (3x3/1x1, stride 1/2; nbdt/models/resnet.py:47-66), its dgrad (flipped taps,
+ * parity classes for stride 2) and the 1x1 shortcut, replacing cuDNN/MIOpen.           */
+typedef struct nbdt_conv_desc {
+  int32_t B, gh, gw;            /* pixel grid of this launch: M = B*gh*gw */
+  int32_t cin, cout;            /* cin % 32 == 0, cout % 32 == 0 */
+  int32_t ntaps;                /* <= 9 */
+  int32_t tap_off[9];           /* element offset added to the input pixel offset */
+  int32_t w_tap[9];             /* tap index into the weight tensor */
+  int32_t w_ntaps;              /* taps stored in the weight tensor (row length = w_ntaps*cin) */
+  int32_t in_bs, in_hs, in_ws, in_base;      /* element strides of the input pixel map */
+  int32_t out_bs, out_hs, out_ws, out_base;  /* element strides of the output pixel map */
+  int32_t accumulate;           /* 1: out += result (reads out) */
+} nbdt_conv_desc;
+/* in/out/w bf16; residual (nullable) bf16 addressed like out and added before rounding */
+int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                    const void* residual, void* stream);
+
+/* weight gradient (replaces cuDNN wgrad): dw[cout][w_ntaps][cin] fp32 += sum over the pixel grid
+ * of gy[pix_g(m)][co] * x[pix_x(m) + tap_off[t]][ci]; split over pixels with fp32 atomics, so dw
+ * must be zeroed (or hold the running .grad) before the call. */
+typedef struct nbdt_wgrad_desc {
+  int32_t B, gh, gw;
+  int32_t cin, cout;
+  int32_t ntaps;
+  int32_t tap_off[9];
+  int32_t w_tap[9];
+  int32_t w_ntaps;
+  int32_t x_bs, x_hs, x_ws, x_base;
+  int32_t g_bs, g_hs, g_ws, g_base;
+} nbdt_wgrad_desc;
+int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw,
+                    void* stream);
+
+/* fp32 master [cout][taps][cin] -> bf16 copy in the same order, and (optional) the dgrad copy
+ * wd[cin][taps][cout] with the tap order reversed (wd[ci][t][co] = w[co][taps-1-t][ci]) */
+int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, void* w_bf16,
+                     void* wd_bf16, void* stream);
+
+/* ------------------------------------------------------------------ backbone: batch-norm / elementwise
+ * Tensors are padded NHWC bf16 [B][H+2][W+2][C]; only interiors are read/written.
+ * stats: [2][C] fp32 (sum, sum of squares) accumulated with atomics -> zero it first. */
+int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float* stats,
+                  void* stream);
+/* y = relu?( (x-mean)*rstd*gamma + beta [+ residual] ); train-mode batch statistics from `stats`
+ * (nn.BatchNorm2d eps 1e-5); also writes save_mean/save_rstd [C] and updates running stats with
+ * momentum (unbiased variance) when running_mean != NULL. */
+int nbdt_bn_apply(const void* x, const float* stats, const float* gamma, const float* beta,
+                  const void* residual, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
+                  float eps, float momentum, float* running_mean, float* running_var,
+                  float* save_mean, float* save_rstd, void* y, void* stream);
+/* backward of bn_apply: gy masked by (y>0) when relu; pass 1 accumulates dgamma/dbeta
+ * (dstats[2][C]: sum gy, sum gy*xhat; zero first), pass 2 writes
+ * gx = gamma*rstd*(gy - (dbeta + xhat*dgamma)/N) [+ gx_add]; g_resid (nullable) receives the
+ * masked gy (gradient of the residual input). */
+int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float* save_mean,
+                       const float* save_rstd, int32_t relu, int32_t B, int32_t H, int32_t W,
+                       int32_t C, float* dstats, void* stream);
+int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float* save_mean,
+                      const float* save_rstd, const float* gamma, const float* dstats,
+                      const void* gx_add, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
+                      void* gx, void* g_resid, float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------ stem / head / optimizer */
+/* stem Conv2d(3->cout_real, 3x3, pad 1) on NCHW fp32 images -> padded NHWC bf16 with `cpad`
+ * channels (channels >= cout_real are zero).  w: fp32 [cout_real][3][3][3] (co, r, s, ci). */
+int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32_t W,
+                   int32_t cout_real, int32_t cpad, void* out, void* stream);
+int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int32_t H, int32_t W,
+                    int32_t cout_real, int32_t cpad, float* dw, void* stream);
+/* global average pool of relu(bn(x)) (post_activ + final_pool): pooled[B][C] fp32 */
+int nbdt_bn_relu_pool(const void* x, const float* stats, const float* gamma, const float* beta,
+                      int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
+                      float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                      float* pooled, void* stream);
+/* backward of the above given gpooled[B][C]: two passes like bn_bwd_* with gy = gpooled/(H*W) */
+int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, const float* save_mean,
+                            const float* save_rstd, const float* gamma, const float* beta,
+                            int32_t B, int32_t H, int32_t W, int32_t C, float* dstats, void* stream);
+int nbdt_pool_bn_bwd_apply(const float* gpooled, const void* x, const float* save_mean,
+                           const float* save_rstd, const float* gamma, const float* beta,
+                           const float* dstats, int32_t B, int32_t H, int32_t W, int32_t C, void* gx,
+                           float* dgamma, float* dbeta, void* stream);
+/* nn.Linear: z[B][N] = x[B][K] w[N][K]^T + b (fp32) and its backward */
+int nbdt_linear_fwd(const float* x, const float* w, const float* b, int32_t B, int32_t K, int32_t N,
+                    float* z, void* stream);
+int nbdt_linear_bwd(const float* x, const float* w, const float* gz, int32_t B, int32_t K, int32_t N,
+                    float* gx, float* gw, float* gb, void* stream);
+/* optim.SGD(momentum, weight_decay) over a flat fp32 buffer (main.py:207):
+ * g += wd*p; buf = mom*buf + g; p -= lr*buf   (grad_scale multiplies g first) */
+int nbdt_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                  float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBDT_HIP_H */

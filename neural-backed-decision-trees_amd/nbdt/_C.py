@@ -1,0 +1,246 @@
+"""ctypes binding of libnbdt_hip.so (include/nbdt_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or a call is made without a HIP
+device, the product path raises.  (The CPU oracle under ``oracle/`` is test infrastructure and
+is never imported from here.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+_LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libnbdt_hip.so")
+_lib = None
+
+NBDT_F32, NBDT_BF16, NBDT_F16 = 0, 1, 2
+_ZTYPE = {torch.float32: NBDT_F32, torch.bfloat16: NBDT_BF16, torch.float16: NBDT_F16}
+
+
+class NBDTHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", c_int32), ("gh", c_int32), ("gw", c_int32),
+        ("cin", c_int32), ("cout", c_int32),
+        ("ntaps", c_int32),
+        ("tap_off", c_int32 * 9), ("w_tap", c_int32 * 9), ("w_ntaps", c_int32),
+        ("in_bs", c_int32), ("in_hs", c_int32), ("in_ws", c_int32), ("in_base", c_int32),
+        ("out_bs", c_int32), ("out_hs", c_int32), ("out_ws", c_int32), ("out_base", c_int32),
+        ("accumulate", c_int32),
+    ]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", c_int32), ("gh", c_int32), ("gw", c_int32),
+        ("cin", c_int32), ("cout", c_int32),
+        ("ntaps", c_int32),
+        ("tap_off", c_int32 * 9), ("w_tap", c_int32 * 9), ("w_ntaps", c_int32),
+        ("x_bs", c_int32), ("x_hs", c_int32), ("x_ws", c_int32), ("x_base", c_int32),
+        ("g_bs", c_int32), ("g_hs", c_int32), ("g_ws", c_int32), ("g_base", c_int32),
+    ]
+
+
+_P = c_void_p
+_I32P = POINTER(c_int32)
+
+# name -> (restype, argtypes): every symbol include/nbdt_hip.h declares
+SIGNATURES = {
+    "nbdt_last_error": (c_char_p, []),
+    "nbdt_version": (c_int, []),
+    "nbdt_device_count": (c_int, []),
+    "nbdt_tree_create": (c_int, [c_int, c_int, c_int, c_int, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P,
+                                 POINTER(c_void_p)]),
+    "nbdt_tree_destroy": (c_int, [c_void_p]),
+    "nbdt_tree_max_depth": (c_int, [c_void_p]),
+    "nbdt_soft_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P]),
+    "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
+    "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,
+                                    _P, _P, _P, _P]),
+    "nbdt_hard_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "nbdt_node_outputs": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    "nbdt_conv_igemm": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "nbdt_conv_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
+    "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "nbdt_bn_stats": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                              c_float, _P, _P, _P, _P, _P, _P]),
+    "nbdt_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, _P, _P, _P, _P, _P]),
+    "nbdt_stem_conv": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_stem_wgrad": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_relu_pool": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
+                                  _P, _P, _P, _P, _P, _P]),
+    "nbdt_pool_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_pool_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
+                                       _P, _P, _P, _P]),
+    "nbdt_linear_fwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_linear_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
+    "nbdt_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P]),
+}
+
+
+def _missing(name):
+    def raiser(*_a, **_k):
+        raise NBDTHipError(f"{_LIBPATH} does not export {name}: stale build, re-run build()")
+    return raiser
+
+
+def exported_symbols():
+    """Names from SIGNATURES the loaded library really exports (used by the C-ABI test)."""
+    l = ctypes.CDLL(_LIBPATH)
+    return [n for n in SIGNATURES if hasattr(l, n)]
+
+
+def lib():
+    """Load the shared library (once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise NBDTHipError(
+                f"{_LIBPATH} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the NBDT hot path.")
+        l = ctypes.CDLL(_LIBPATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                setattr(l, name, _missing(name))  # stale .so: fail loudly on first use
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def libpath():
+    return _LIBPATH
+
+
+def check(rc):
+    if rc != 0:
+        raise NBDTHipError(f"libnbdt_hip error {rc}: {lib().nbdt_last_error().decode()}")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise NBDTHipError(
+            f"{what}: tensor is on {t.device}; the NBDT hot path runs on MI355X only "
+            "(no CPU fallback -- move inputs to a HIP device)")
+
+
+def ztype_of(t):
+    try:
+        return _ZTYPE[t.dtype]
+    except KeyError:
+        raise NBDTHipError(f"unsupported logits dtype {t.dtype}") from None
+
+
+class TreeHandle:
+    """Owns one nbdt_tree on one device."""
+
+    def __init__(self, flat, device_index):
+        self.flat = flat
+        self.device_index = device_index
+        out = c_void_p()
+        as_p = lambda a: a.ctypes.data_as(_I32P)
+        check(lib().nbdt_tree_create(
+            int(device_index), flat.num_classes, flat.num_inodes, flat.root,
+            as_p(flat.node_off), as_p(flat.slot_off), as_p(flat.slot_cls),
+            as_p(flat.cls_off), as_p(flat.cls_slot), as_p(flat.slot_next), ctypes.byref(out)))
+        self.h = out
+        self.max_depth = lib().nbdt_tree_max_depth(self.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and _lib is not None:
+                _lib.nbdt_tree_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _rows(z):
+    """[B, C] tensor with unit column stride -> (tensor, B, ldz)."""
+    if z.dim() != 2:
+        raise NBDTHipError(f"rules layer expects [B, C] logits, got shape {tuple(z.shape)}")
+    if z.stride(1) != 1 or (z.shape[0] > 1 and z.stride(0) < z.shape[1]):
+        z = z.contiguous()
+    return z, z.shape[0], (z.stride(0) if z.shape[0] > 1 else z.shape[1])
+
+
+def soft_forward(handle, z):
+    require_gpu(z, "soft_forward")
+    z, B, ld = _rows(z)
+    P = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
+    check(lib().nbdt_soft_forward(handle.h, ptr(z), ztype_of(z), B, ld, ptr(P), stream_of(z)))
+    return P
+
+
+def soft_backward(handle, z, gP):
+    require_gpu(z, "soft_backward")
+    z, B, ld = _rows(z)
+    gP = gP.contiguous().float()
+    gz = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
+    check(lib().nbdt_soft_backward(handle.h, ptr(z), ztype_of(z), B, ld, ptr(gP), ptr(gz), stream_of(z)))
+    return gz
+
+
+def soft_tree_loss(handle, z, y, w_xent, w_tree, grad_scale=1.0):
+    """Returns (loss scalar tensor, gz [B,C] fp32)."""
+    require_gpu(z, "soft_tree_loss")
+    z, B, ld = _rows(z)
+    y = y.to(device=z.device, dtype=torch.int64).contiguous()
+    row = torch.empty((B,), dtype=torch.float32, device=z.device)
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    gz = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
+    check(lib().nbdt_soft_tree_loss(handle.h, ptr(z), ztype_of(z), B, ld, ptr(y), float(w_xent),
+                                    float(w_tree), float(grad_scale), ptr(row), ptr(loss), ptr(gz),
+                                    stream_of(z)))
+    return loss, gz
+
+
+def hard_forward(handle, z, want_onehot=True, want_decisions=False):
+    require_gpu(z, "hard_forward")
+    z, B, ld = _rows(z)
+    C, D = handle.flat.num_classes, handle.max_depth
+    dev = z.device
+    pred = torch.empty((B,), dtype=torch.int64, device=dev)
+    onehot = torch.empty((B, C), dtype=torch.float32, device=dev) if want_onehot else None
+    if want_decisions:
+        pn = torch.empty((B, D), dtype=torch.int32, device=dev)
+        pc = torch.empty((B, D), dtype=torch.int32, device=dev)
+        pp = torch.empty((B, D), dtype=torch.float32, device=dev)
+        pe = torch.empty((B, D), dtype=torch.float32, device=dev)
+    else:
+        pn = pc = pp = pe = None
+    check(lib().nbdt_hard_forward(handle.h, ptr(z), ztype_of(z), B, ld, ptr(pred), ptr(onehot), ptr(pn),
+                                  ptr(pc), ptr(pp), ptr(pe), stream_of(z)))
+    return pred, onehot, (pn, pc, pp, pe)
+
+
+def node_outputs(handle, z):
+    require_gpu(z, "node_outputs")
+    z, B, ld = _rows(z)
+    R, N = handle.flat.num_slots, handle.flat.num_inodes
+    dev = z.device
+    logits = torch.empty((B, R), dtype=torch.float32, device=dev)
+    probs = torch.empty((B, R), dtype=torch.float32, device=dev)
+    preds = torch.empty((B, N), dtype=torch.int64, device=dev)
+    ent = torch.empty((B, N), dtype=torch.float32, device=dev)
+    check(lib().nbdt_node_outputs(handle.h, ptr(z), ztype_of(z), B, ld, ptr(logits), ptr(probs),
+                                  ptr(preds), ptr(ent), stream_of(z)))
+    return logits, probs, preds, ent

@@ -1,0 +1,166 @@
+"""Tree-supervision losses, MI355X-native.
+
+Drop-in surface of the reference's ``nbdt/loss.py``: ``TreeSupLoss`` (:97-209) and
+``SoftTreeSupLoss`` (:260-266) with the same constructor arguments, ``accepts_*`` class
+attributes (used by the reference's ``main.py`` flag plumbing), ``set_epoch`` / ``get_weight``
+weight schedule and the ``_nbdt_output_flag`` guard.
+
+When the wrapped criterion is a default ``nn.CrossEntropyLoss()`` the whole loss --
+``w_x*CE(z,y) + w_t*CE(rules(z), y)`` and its gradient -- is ONE fused HIP kernel
+(csrc/rules.hip: soft_loss_kernel).  Any other criterion composes the fused rules kernel
+(autograd-enabled) with the user's criterion, exactly like the reference.
+
+``HardTreeSupLoss`` and ``SoftTreeLoss`` are "next" rows and raise.
+"""
+import torch
+import torch.nn as nn
+
+from nbdt import _C
+from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules
+from nbdt.tree import Tree
+
+__all__ = names = ("HardTreeSupLoss", "SoftTreeSupLoss", "SoftTreeLoss", "CrossEntropyLoss")
+
+CrossEntropyLoss = nn.CrossEntropyLoss
+
+
+def _is_plain_cross_entropy(criterion):
+    return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None
+            and criterion.reduction == "mean" and criterion.ignore_index == -100
+            and getattr(criterion, "label_smoothing", 0.0) == 0.0)
+
+
+class _FusedSoftTreeLossFn(torch.autograd.Function):
+    """loss, and dloss/dz computed in the same launch (saved for backward)."""
+
+    @staticmethod
+    def forward(ctx, z, y, tree, w_xent, w_tree):
+        handle = tree.device_handle(z.device.index)
+        loss, gz = _C.soft_tree_loss(handle, z, y, w_xent, w_tree)
+        ctx.save_for_backward(gz)
+        ctx.z_dtype = z.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (gz,) = ctx.saved_tensors
+        return (gz * gloss).to(ctx.z_dtype), None, None, None, None
+
+
+class TreeSupLoss(nn.Module):
+    """reference nbdt/loss.py:97-209."""
+
+    accepts_tree = lambda tree, **kwargs: tree
+    accepts_criterion = lambda criterion, **kwargs: criterion
+    accepts_dataset = lambda trainset, **kwargs: trainset.__class__.__name__
+    accepts_path_graph = True
+    accepts_path_wnids = True
+    accepts_tree_supervision_weight = True
+    accepts_classes = lambda trainset, **kwargs: trainset.classes
+    accepts_hierarchy = True
+    accepts_tree_supervision_weight_end = True
+    accepts_tree_supervision_weight_power = True
+    accepts_xent_weight = True
+    accepts_xent_weight_end = True
+    accepts_xent_weight_power = True
+
+    def __init__(self, dataset, criterion, path_graph=None, path_wnids=None, classes=None,
+                 hierarchy=None, Rules=HardEmbeddedDecisionRules, tree=None,
+                 tree_supervision_weight=1.0, tree_supervision_weight_end=None,
+                 tree_supervision_weight_power=1, xent_weight=1, xent_weight_end=None,
+                 xent_weight_power=1):
+        super().__init__()
+        if not tree:
+            tree = Tree(dataset, path_graph, path_wnids, classes, hierarchy=hierarchy)
+        self.num_classes = len(tree.classes)
+        self.tree = tree
+        self.rules = Rules(tree=tree)
+        self.tree_supervision_weight = tree_supervision_weight
+        self.tree_supervision_weight_end = (
+            tree_supervision_weight_end if tree_supervision_weight_end is not None
+            else tree_supervision_weight)
+        self.tree_supervision_weight_power = tree_supervision_weight_power
+        self.xent_weight = xent_weight
+        self.xent_weight_end = xent_weight_end if xent_weight_end is not None else xent_weight
+        self.xent_weight_power = xent_weight_power
+        self.criterion = criterion
+        self.progress = 1
+        self.epochs = 0
+
+    @staticmethod
+    def assert_output_not_nbdt(outputs):
+        assert getattr(outputs, "_nbdt_output_flag", False) is False, (
+            "Uh oh! Looks like you passed an NBDT model's output to an NBDT "
+            "loss. NBDT losses are designed to take in the *original* model's "
+            "outputs, as input. NBDT models are designed to only be used "
+            "during validation and inference, not during training. Confused? "
+            " Check out github.com/alvinwan/nbdt#convert-neural-networks-to-decision-trees"
+            " for examples and instructions.")
+
+    def forward_tree(self, outputs, targets):
+        raise NotImplementedError()
+
+    def get_weight(self, start, end, power=1):
+        progress = self.progress ** power
+        return (1 - progress) * start + progress * end
+
+    def current_weights(self):
+        """(xent_weight, tree_weight) at the current epoch progress (reference :195-202)."""
+        tree_weight = self.get_weight(self.tree_supervision_weight, self.tree_supervision_weight_end,
+                                      self.tree_supervision_weight_power)
+        xent_weight = self.get_weight(self.xent_weight, self.xent_weight_end, self.xent_weight_power)
+        return xent_weight, tree_weight
+
+    def forward(self, outputs, targets):
+        loss_xent = self.criterion(outputs, targets)
+        loss_tree = self.forward_tree(outputs, targets)
+        xent_weight, tree_weight = self.current_weights()
+        return loss_xent * xent_weight + loss_tree * tree_weight
+
+    def set_epoch(self, cur, total):
+        self.epochs = cur
+        self.progress = cur / total
+        if hasattr(super(), "set_epoch"):
+            super().set_epoch(cur, total)
+
+
+class SoftTreeSupLoss(TreeSupLoss):
+    """reference nbdt/loss.py:260-266."""
+
+    def __init__(self, *args, Rules=None, **kwargs):
+        super().__init__(*args, Rules=SoftEmbeddedDecisionRules, **kwargs)
+
+    def forward_tree(self, outputs, targets):
+        self.assert_output_not_nbdt(outputs)
+        return self.criterion(self.rules(outputs), targets)
+
+    def forward(self, outputs, targets):
+        if _is_plain_cross_entropy(self.criterion) and outputs.dim() == 2:
+            self.assert_output_not_nbdt(outputs)
+            _C.require_gpu(outputs, "SoftTreeSupLoss")
+            xent_weight, tree_weight = self.current_weights()
+            return _FusedSoftTreeLossFn.apply(outputs, targets, self.tree, float(xent_weight),
+                                              float(tree_weight))
+        return super().forward(outputs, targets)
+
+    def loss_and_grad(self, outputs, targets, grad_scale=1.0):
+        """Engine fast path: (loss, dloss/dz * grad_scale) from one launch, no autograd."""
+        self.assert_output_not_nbdt(outputs)
+        xent_weight, tree_weight = self.current_weights()
+        handle = self.tree.device_handle(outputs.device.index)
+        return _C.soft_tree_loss(handle, outputs, targets, float(xent_weight), float(tree_weight),
+                                 grad_scale)
+
+
+class HardTreeSupLoss(TreeSupLoss):
+    """reference nbdt/loss.py:212-257 -- scheduled after the soft path."""
+
+    def forward_tree(self, outputs, targets):
+        raise NotImplementedError("HardTreeSupLoss is not built yet (SURVEY.md section 8f, rank 1)")
+
+
+class SoftTreeLoss(SoftTreeSupLoss):
+    """reference nbdt/loss.py:269-315 re-induces the hierarchy mid-training (out of scope)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("SoftTreeLoss (mid-training hierarchy re-induction) is out of scope")

@@ -1,0 +1,204 @@
+"""Parity of the HIP rules layer / SoftTreeSupLoss (through the C-ABI) against the CPU oracle and
+against the reference's golden vectors.  Integer outputs are bit-exact; fp32 tolerances are the
+ones stated in SURVEY.md 8c: P rtol 2e-5 / atol 1e-6, loss 1e-5 rel, dL/dz 1e-6 abs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import nbdt_oracle as O
+from conftest import GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+
+from nbdt import _C  # noqa: E402
+from nbdt.loss import SoftTreeSupLoss  # noqa: E402
+from nbdt.model import (HardEmbeddedDecisionRules, HardNBDT, SoftEmbeddedDecisionRules,  # noqa: E402
+                        SoftNBDT)
+from nbdt.tree import Tree  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _case(tag, golden_dir, pkg_dir):
+    ds, h = GOLDEN_CASES[tag]
+    g = np.load(os.path.join(golden_dir, f"rules_{tag}.npz"))
+    return g, Tree(ds, hierarchy=h), O.OracleTree(*O.default_paths(ds, h, pkg_dir)), ds, h
+
+
+@pytest.mark.parametrize("tag", list(GOLDEN_CASES))
+def test_golden_inputs(tag, golden_dir, pkg_dir):
+    g, tree, otree, ds, h = _case(tag, golden_dir, pkg_dir)
+    z = torch.from_numpy(g["z"]).to(DEV)
+    y = torch.from_numpy(g["y"]).to(DEV)
+    handle = tree.device_handle(0)
+
+    P = _C.soft_forward(handle, z).cpu().numpy()
+    outs = O.node_outputs(otree, g["z"])
+    Po = O.soft_forward(otree, g["z"], outs)
+    np.testing.assert_allclose(P, Po, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(P, g["soft_P"], rtol=2e-5, atol=1e-6)
+    assert np.array_equal(P.argmax(1), g["soft_P"].argmax(1))
+
+    pred, onehot, (pn, pc, pp, pe) = _C.hard_forward(handle, z, want_onehot=True, want_decisions=True)
+    pred = pred.cpu().numpy()
+    assert np.array_equal(pred, O.hard_forward(otree, g["z"], outs))       # bit-exact vs oracle
+    assert np.array_equal(pred, g["hard_pred"])                             # and vs the reference
+    oh = onehot.cpu().numpy()
+    assert np.array_equal(oh, np.eye(oh.shape[1], dtype=np.float32)[pred])
+    D = min(pn.shape[1], 32)
+    assert np.array_equal(pn.cpu().numpy()[:4, :D], g["dec_path"][:, :D])
+    assert np.array_equal(pc.cpu().numpy()[:4, :D], g["dec_next"][:, :D])
+    np.testing.assert_allclose(pp.cpu().numpy()[:4, :D], g["dec_prob"][:, :D], atol=1e-6)
+    np.testing.assert_allclose(pe.cpu().numpy()[:4, :D], g["dec_entropy"][:, :D], atol=1e-5)
+    assert (g["dec_path"][:, D:] < 0).all()
+
+    for (wx, wt, kl, kd) in [(1.0, 1.0, "loss", "dz"), (0.5, 10.0, "loss_w", "dz_w")]:
+        loss, gz = _C.soft_tree_loss(handle, z, y, wx, wt)
+        lo, dzo = O.soft_tree_sup_loss(otree, g["z"], g["y"], wx, wt)
+        assert abs(loss.item() - lo) <= 1e-5 * abs(lo)
+        assert abs(loss.item() - g[kl]) <= 1e-5 * abs(g[kl])
+        np.testing.assert_allclose(gz.cpu().numpy(), dzo, atol=1e-6, rtol=0)
+        np.testing.assert_allclose(gz.cpu().numpy(), g[kd], atol=1e-6, rtol=0)
+
+    gz = _C.soft_backward(handle, z, torch.from_numpy(g["gP"]).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(gz, g["dz_rules"], atol=2e-6, rtol=1e-5)
+
+    logits, probs, preds, ent = (t.cpu().numpy() for t in _C.node_outputs(handle, z))
+    assert np.array_equal(logits, np.concatenate([o["logits"] for o in outs], 1))  # same fp32 order
+    np.testing.assert_allclose(probs, g["node_probs"], rtol=2e-5, atol=1e-6)
+    assert np.array_equal(preds, g["node_preds"])
+    np.testing.assert_allclose(ent, g["node_entropy"], rtol=1e-4, atol=1e-6)
+
+
+# BASELINE.json shapes: (B, dataset, hierarchy)
+FULL = [(512, "CIFAR10", "induced-wrn28_10_cifar10"), (1024, "CIFAR100", "induced-wrn28_10_cifar100"),
+        (1024, "TinyImagenet200", "induced-ResNet18"), (256, "Imagenet1000", "induced-efficientnet_b7b")]
+
+
+@pytest.mark.parametrize("B,ds,h", FULL)
+def test_full_size_vs_oracle(B, ds, h, pkg_dir):
+    tree = Tree(ds, hierarchy=h)
+    otree = O.OracleTree(*O.default_paths(ds, h, pkg_dir))
+    C = len(tree.classes)
+    gen = torch.Generator().manual_seed(B + C)
+    z = torch.randn(B, C, generator=gen) * 3
+    y = torch.randint(0, C, (B,), generator=gen)
+    zd, yd = z.to(DEV), y.to(DEV)
+    handle = tree.device_handle(0)
+    outs = O.node_outputs(otree, z.numpy())
+    P = _C.soft_forward(handle, zd).cpu().numpy()
+    np.testing.assert_allclose(P, O.soft_forward(otree, z.numpy(), outs), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(P.sum(1), 1.0, atol=2e-5)          # size-independent property
+    pred = _C.hard_forward(handle, zd, want_onehot=False)[0].cpu().numpy()
+    assert np.array_equal(pred, O.hard_forward(otree, z.numpy(), outs))
+    loss, gz = _C.soft_tree_loss(handle, zd, yd, 1.0, 1.0)
+    lo, dzo = O.soft_tree_sup_loss(otree, z.numpy(), y.numpy())
+    assert abs(loss.item() - lo) <= 1e-5 * abs(lo)
+    np.testing.assert_allclose(gz.cpu().numpy(), dzo, atol=1e-6, rtol=0)
+    # gradient rows of a softmax-CE sum to ~0 (both terms): property check at full size
+    assert np.abs(gz.cpu().numpy().sum(1)).max() < 1e-6
+
+
+def test_edge_cases(pkg_dir):
+    tree = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))
+    handle = tree.device_handle(0)
+    # empty batch
+    z0 = torch.empty(0, 10, device=DEV)
+    assert _C.soft_forward(handle, z0).shape == (0, 10)
+    assert _C.hard_forward(handle, z0)[0].shape == (0,)
+    # all-zero logits: every node ties -> child 0 -> class 4
+    z = torch.zeros(3, 10, device=DEV)
+    assert _C.hard_forward(handle, z)[0].tolist() == [4, 4, 4]
+    # B = 1 and ragged batch (not a multiple of the samples-per-block)
+    for B in (1, 5, 7):
+        zz = torch.randn(B, 10, generator=torch.Generator().manual_seed(B))
+        P = _C.soft_forward(handle, zz.to(DEV)).cpu().numpy()
+        np.testing.assert_allclose(P, O.soft_forward(otree, zz.numpy()), rtol=2e-5, atol=1e-6)
+    # row stride > C (a column slice of a wider matrix) is consumed in place
+    wide = torch.randn(9, 16, generator=torch.Generator().manual_seed(3)).to(DEV)
+    view = wide[:, :10]
+    P = _C.soft_forward(handle, view).cpu().numpy()
+    np.testing.assert_allclose(P, O.soft_forward(otree, view.cpu().numpy()), rtol=2e-5, atol=1e-6)
+    # bf16 / fp16 logits are up-cast on load, P stays fp32 (boundary contract 7)
+    for dt in (torch.bfloat16, torch.float16):
+        zb = torch.randn(6, 10, generator=torch.Generator().manual_seed(9)).to(dt)
+        P = _C.soft_forward(handle, zb.to(DEV))
+        assert P.dtype == torch.float32
+        np.testing.assert_allclose(P.cpu().numpy(), O.soft_forward(otree, zb.float().numpy()),
+                                   rtol=2e-5, atol=1e-6)
+    # huge logits do not overflow
+    zh = torch.zeros(2, 10); zh[0, 3] = 1e4; zh[1, 7] = -1e4
+    P = _C.soft_forward(handle, zh.to(DEV)).cpu().numpy()
+    assert np.isfinite(P).all() and P[0].argmax() == 3
+    # invalid label -> NaN loss (loud), not silent garbage
+    loss, _ = _C.soft_tree_loss(handle, torch.zeros(2, 10, device=DEV), torch.tensor([1, 10], device=DEV), 1, 1)
+    assert torch.isnan(loss).item()
+    # CPU tensors are refused: there is no CPU fallback
+    with pytest.raises(_C.NBDTHipError):
+        _C.soft_forward(handle, torch.zeros(2, 10))
+
+
+def test_module_api_matches_reference_contracts(pkg_dir):
+    torch.manual_seed(0)
+    backbone = nn.Linear(32, 10).to(DEV)
+    x = torch.randn(16, 32, device=DEV)
+    y = torch.randint(0, 10, (16,), device=DEV)
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-ResNet18", pkg_dir))
+
+    soft = SoftNBDT("CIFAR10", backbone, arch="ResNet18")          # hierarchy = induced-ResNet18
+    hard = HardNBDT("CIFAR10", backbone, hierarchy="induced-ResNet18")
+    assert not soft.training and isinstance(soft.rules, SoftEmbeddedDecisionRules)
+    assert isinstance(hard.rules, HardEmbeddedDecisionRules)
+    assert set(soft.state_dict()) == set(backbone.state_dict())   # proxied to the backbone
+    z = backbone(x)
+    P = soft(x)
+    assert getattr(P, "_nbdt_output_flag", False) is True and P.dtype == torch.float32
+    np.testing.assert_allclose(P.detach().cpu().numpy(), O.soft_forward(otree, z.detach().cpu().numpy()),
+                               rtol=2e-5, atol=1e-6)
+    H = hard(x)
+    assert H._nbdt_output_flag and not H.requires_grad
+    assert np.array_equal(H.argmax(1).cpu().numpy(), O.hard_forward(otree, z.detach().cpu().numpy()))
+    H2, decisions = hard.forward_with_decisions(x)
+    assert torch.equal(H, H2) and len(decisions) == 16 and decisions[0][0]["name"] == "root"
+    for dec, p in zip(decisions, H.argmax(1).tolist()):
+        assert dec[-1]["node"].wnid == soft.rules.tree.wnids_leaves[p]
+    Ps, sdec = soft.forward_with_decisions(x)
+    assert len(sdec) == 16 and abs(np.prod([s["prob"] for s in sdec[3]]) - Ps[3].max().item()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        SoftNBDT("CIFAR10", "ResNet18", arch="ResNet18")
+    with pytest.raises(UserWarning):
+        SoftNBDT("CIFAR10", backbone, pretrained=True, hierarchy="induced")
+
+    # losses: fused path == composed path == oracle; NBDT outputs are rejected
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18",
+                           tree_supervision_weight=2.0)
+    z1 = z.detach().clone().requires_grad_(True)
+    l1 = crit(z1, y)
+    l1.backward()
+    lo, dzo = O.soft_tree_sup_loss(otree, z.detach().cpu().numpy(), y.cpu().numpy(), 1.0, 2.0)
+    assert abs(l1.item() - lo) <= 1e-5 * abs(lo)
+    np.testing.assert_allclose(z1.grad.cpu().numpy(), dzo, atol=1e-6, rtol=0)
+
+    class MyCE(nn.CrossEntropyLoss):  # not `type(...) is CrossEntropyLoss` -> composed autograd path
+        pass
+
+    crit2 = SoftTreeSupLoss(dataset="CIFAR10", criterion=MyCE(), hierarchy="induced-ResNet18",
+                            tree_supervision_weight=2.0)
+    z2 = z.detach().clone().requires_grad_(True)
+    l2 = crit2(z2, y)
+    l2.backward()
+    assert abs(l2.item() - lo) <= 1e-5 * abs(lo)
+    np.testing.assert_allclose(z2.grad.cpu().numpy(), dzo, atol=2e-6, rtol=0)
+    with pytest.raises(AssertionError):
+        crit(P, y)
+    # epoch-dependent weights (nbdt/loss.py:187-189, 205-207)
+    crit3 = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18",
+                            tree_supervision_weight=1.0, tree_supervision_weight_end=5.0)
+    crit3.set_epoch(5, 10)
+    l3 = crit3(z.detach(), y)
+    lo3, _ = O.soft_tree_sup_loss(otree, z.detach().cpu().numpy(), y.cpu().numpy(), 1.0, 3.0)
+    assert abs(l3.item() - lo3) <= 1e-5 * abs(lo3)

@@ -1,0 +1,57 @@
+"""Host logic: our Tree/Node/FlatTree against the reference Tree recorded in the golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES
+from nbdt.tree import Tree
+
+
+@pytest.mark.parametrize("tag", list(GOLDEN_CASES))
+def test_flat_tree_matches_reference(tag, golden_dir):
+    ds, h = GOLDEN_CASES[tag]
+    g = np.load(os.path.join(golden_dir, f"rules_{tag}.npz"))
+    tree = Tree(ds, hierarchy=h)
+    flat = tree.flat
+    assert [n.wnid for n in tree.inodes] == list(g["tree_inode_wnids"])
+    assert tree.root.wnid == str(g["tree_root"])
+    assert tree.wnids_leaves == list(g["tree_wnids_leaves"])
+    assert np.array_equal(flat.node_off, g["tree_child_off"])
+    assert np.array_equal(flat.slot_off, g["tree_slot_off"])
+    assert np.array_equal(flat.slot_cls, g["tree_slot_cls"])
+    child_wnid = [c.wnid for n in tree.inodes for c in n.children]
+    assert child_wnid == list(g["tree_child_wnid"])
+    # class -> slots is the transpose of slot -> classes, in inode order
+    for c in range(flat.num_classes):
+        slots = flat.cls_slot[flat.cls_off[c]:flat.cls_off[c + 1]]
+        assert list(slots) == sorted(slots)
+        for s in slots:
+            assert c in flat.slot_cls[flat.slot_off[s]:flat.slot_off[s + 1]]
+    assert flat.cls_off[-1] == flat.slot_off[-1]
+    # slot_next: inner child -> inode index, leaf child -> -(class)-1
+    index = {w: i for i, w in enumerate(flat.inode_wnids)}
+    for s, w in enumerate(child_wnid):
+        if w in index:
+            assert flat.slot_next[s] == index[w]
+        else:
+            assert flat.slot_next[s] == -tree.wnid_to_class_index[w] - 1
+
+
+def test_reference_api_surface():
+    tree = Tree("CIFAR10", hierarchy="induced-ResNet18")
+    assert len(tree.classes) == 10 and tree.classes[3] == "f00000003"
+    root = tree.root
+    assert root.is_root() and not root.is_leaf() and root.num_classes == len(root.children) == 2
+    assert sorted(sum((root.child_index_to_class_index[k] for k in range(2)), [])) == list(range(10))
+    for c, ks in root.class_index_to_child_index.items():
+        assert len(ks) == 1 and c in root.child_index_to_class_index[ks[0]]
+    steps = tree.get_leaf_to_steps()
+    assert set(steps) == set(tree.wnids_leaves)
+    for leaf, path in steps.items():
+        assert path[0]["node"] is root and path[-1]["next_index"] == -1
+        assert path[-1]["node"].wnid == leaf
+    # default hierarchy resolution (nbdt/utils.py:62-71)
+    assert Tree("CIFAR100").path_graph.endswith("hierarchies/CIFAR100/graph-induced.json")
+    with pytest.raises(FileNotFoundError):
+        Tree("CIFAR10", hierarchy="does-not-exist")

@@ -135,28 +135,45 @@ int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, vo
                      void* wd_bf16, void* stream);
 
 /* ------------------------------------------------------------------ backbone: batch-norm / elementwise
- * Tensors are padded NHWC bf16 [B][H+2][W+2][C]; only interiors are read/written.
- * stats: [2][C] fp32 (sum, sum of squares) accumulated with atomics -> zero it first. */
-int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float* stats,
-                  void* stream);
-/* y = relu?( (x-mean)*rstd*gamma + beta [+ residual] ); train-mode batch statistics from `stats`
- * (nn.BatchNorm2d eps 1e-5); also writes save_mean/save_rstd [C] and updates running stats with
- * momentum (unbiased variance) when running_mean != NULL. */
-int nbdt_bn_apply(const void* x, const float* stats, const float* gamma, const float* beta,
-                  const void* residual, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
-                  float eps, float momentum, float* running_mean, float* running_var,
-                  float* save_mean, float* save_rstd, void* y, void* stream);
-/* backward of bn_apply: gy masked by (y>0) when relu; pass 1 accumulates dgamma/dbeta
- * (dstats[2][C]: sum gy, sum gy*xhat; zero first), pass 2 writes
- * gx = gamma*rstd*(gy - (dbeta + xhat*dgamma)/N) [+ gx_add]; g_resid (nullable) receives the
- * masked gy (gradient of the residual input). */
+ * Replaces nn.BatchNorm2d (train mode, eps 1e-5, momentum 0.1) + F.relu + residual adds
+ * (nbdt/models/resnet.py:69-74; pytorchcv PreResUnit) and their autograd.  Tensors are padded
+ * NHWC bf16 [B][H+2][W+2][C], C % 8 == 0; only interiors are read/written.  `scratch` is
+ * NBDT_BN_SLOTS*2*C fp32 of caller-owned workspace (contents overwritten). */
+#define NBDT_BN_SLOTS 32
+/* batch statistics: save_mean/save_rstd [C]; updates running_mean/var (unbiased var) if non-NULL */
+int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps,
+                  float momentum, float* running_mean, float* running_var, float* scratch,
+                  float* save_mean, float* save_rstd, void* stream);
+/* y = relu?( (x-mean)*rstd*gamma + beta [+ residual] ) */
+int nbdt_bn_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                  const float* beta, const void* residual, int32_t relu, int32_t B, int32_t H,
+                  int32_t W, int32_t C, void* y, void* stream);
+/* backward, pass 1: with gy' = gy * (y > 0) when relu (y = the forward output), writes
+ * dsum[0][c] = sum gy', dsum[1][c] = sum gy' * xhat and accumulates dbeta += dsum[0],
+ * dgamma += dsum[1] (either may be NULL). */
 int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float* save_mean,
                        const float* save_rstd, int32_t relu, int32_t B, int32_t H, int32_t W,
-                       int32_t C, float* dstats, void* stream);
+                       int32_t C, float* scratch, float* dsum, float* dgamma, float* dbeta,
+                       void* stream);
+/* backward, pass 2: gx = gamma*rstd*(gy' - (dsum0 + xhat*dsum1)/N) [+ gx_add];
+ * g_resid (nullable) receives gy' (the gradient of the residual input). */
 int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float* save_mean,
-                      const float* save_rstd, const float* gamma, const float* dstats,
+                      const float* save_rstd, const float* gamma, const float* dsum,
                       const void* gx_add, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
-                      void* gx, void* g_resid, float* dgamma, float* dbeta, void* stream);
+                      void* gx, void* g_resid, void* stream);
+/* head: pooled[b][c] = mean over (h,w) of relu(bn(x))  (post_activ + final_pool / avg_pool2d,
+ * nbdt/models/resnet.py:142) and its backward given gpooled[B][C] (same two passes) */
+int nbdt_bn_relu_pool(const void* x, const float* save_mean, const float* save_rstd,
+                      const float* gamma, const float* beta, int32_t B, int32_t H, int32_t W,
+                      int32_t C, float* pooled, void* stream);
+int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, const float* save_mean,
+                            const float* save_rstd, const float* gamma, const float* beta,
+                            int32_t B, int32_t H, int32_t W, int32_t C, float* scratch, float* dsum,
+                            float* dgamma, float* dbeta, void* stream);
+int nbdt_pool_bn_bwd_apply(const float* gpooled, const void* x, const float* save_mean,
+                           const float* save_rstd, const float* gamma, const float* beta,
+                           const float* dsum, int32_t B, int32_t H, int32_t W, int32_t C, void* gx,
+                           void* stream);
 
 /* ------------------------------------------------------------------ stem / head / optimizer */
 /* stem Conv2d(3->cout_real, 3x3, pad 1) on NCHW fp32 images -> padded NHWC bf16 with `cpad`
@@ -165,28 +182,17 @@ int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32
                    int32_t cout_real, int32_t cpad, void* out, void* stream);
 int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int32_t H, int32_t W,
                     int32_t cout_real, int32_t cpad, float* dw, void* stream);
-/* global average pool of relu(bn(x)) (post_activ + final_pool): pooled[B][C] fp32 */
-int nbdt_bn_relu_pool(const void* x, const float* stats, const float* gamma, const float* beta,
-                      int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
-                      float* running_mean, float* running_var, float* save_mean, float* save_rstd,
-                      float* pooled, void* stream);
-/* backward of the above given gpooled[B][C]: two passes like bn_bwd_* with gy = gpooled/(H*W) */
-int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, const float* save_mean,
-                            const float* save_rstd, const float* gamma, const float* beta,
-                            int32_t B, int32_t H, int32_t W, int32_t C, float* dstats, void* stream);
-int nbdt_pool_bn_bwd_apply(const float* gpooled, const void* x, const float* save_mean,
-                           const float* save_rstd, const float* gamma, const float* beta,
-                           const float* dstats, int32_t B, int32_t H, int32_t W, int32_t C, void* gx,
-                           float* dgamma, float* dbeta, void* stream);
 /* nn.Linear: z[B][N] = x[B][K] w[N][K]^T + b (fp32) and its backward */
 int nbdt_linear_fwd(const float* x, const float* w, const float* b, int32_t B, int32_t K, int32_t N,
                     float* z, void* stream);
 int nbdt_linear_bwd(const float* x, const float* w, const float* gz, int32_t B, int32_t K, int32_t N,
                     float* gx, float* gw, float* gb, void* stream);
 /* optim.SGD(momentum, weight_decay) over a flat fp32 buffer (main.py:207):
- * g += wd*p; buf = mom*buf + g; p -= lr*buf   (grad_scale multiplies g first) */
+ * g = grad_scale*g + wd*p; buf = mom*buf + g; p -= lr*buf; optionally refreshes the bf16 copy the
+ * conv kernels read (same element order as p) in the same pass */
 int nbdt_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
-                  float weight_decay, float grad_scale, void* stream);
+                  float weight_decay, float grad_scale, void* p_bf16 /* nullable: bf16 copy of p */,
+                  void* stream);
 
 #ifdef __cplusplus
 }

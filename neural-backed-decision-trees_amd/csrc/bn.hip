@@ -1,0 +1,449 @@
+// Train-mode BatchNorm2d (+ReLU, +residual, +global-avg-pool head) forward/backward on gfx950.
+//
+// Replaces nn.BatchNorm2d / F.relu / `out += shortcut(x)` / F.avg_pool2d and their autograd on the
+// backbone path (reference nbdt/models/resnet.py:69-74, 136-144; pytorchcv PreResUnit/PreResActivation
+// behind nbdt/models/wideresnet.py:1-5).  All kernels are HBM-bound streaming passes over padded
+// NHWC bf16 tensors: 16-byte (8-channel) vectors per lane, a thread keeps a FIXED channel chunk and
+// walks pixels, so per-channel parameters live in registers and per-channel reductions need no
+// cross-lane traffic until one LDS fold per block.  Per-channel sums go through NBDT_BN_SLOTS
+// replicated accumulators (atomics spread over 32 slots -> no same-address pile-up) and are folded
+// by a 1-block finalize kernel; fp32 throughout.
+//
+// Roofline: HBM.  Algorithmic bytes per element: stats 2 (read x); apply 4 (+2 residual);
+// bwd_reduce 6; bwd_apply 8 (+2 gx_add, +2 g_resid).
+#include "common.h"
+
+using namespace nbdt;
+
+constexpr int kSlots = NBDT_BN_SLOTS;
+constexpr int kMaxThreads = 256;
+
+struct Layout {  // thread layout for a C-channel tensor: C8 channel chunks x PY pixel rows
+  int c8, py, threads;
+};
+static Layout layout_for(int C) {
+  Layout l;
+  l.c8 = C / 8;
+  l.py = kMaxThreads / l.c8;
+  if (l.py < 1) l.py = 1;
+  l.threads = l.c8 * l.py;
+  return l;
+}
+static int grid_for(const PadGeom& g, const Layout& l, int pixels_per_thread) {
+  long long want = ((long long)g.npix + (long long)l.py * pixels_per_thread - 1) / ((long long)l.py * pixels_per_thread);
+  if (want < 1) want = 1;
+  if (want > 2048) want = 2048;
+  return (int)want;
+}
+
+// fold per-thread 8-channel partial sums across the PY pixel rows of the block, then add them
+// to slot (blockIdx & 31) of scratch[slot][which][C]
+template <int NQ>
+__device__ __forceinline__ void block_fold_to_slots(float (&acc)[NQ][8], int cx, int py, int c8, int PY, int C,
+                                                    float* scratch, float* lds) {
+  // lds: [PY][c8][NQ*8]
+  float* mine = lds + ((size_t)py * c8 + cx) * (NQ * 8);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[q * 8 + i] = acc[q][i];
+  __syncthreads();
+  // thread (cx, py) folds element e = py, py+PY, ... of its channel chunk
+  for (int e = py; e < NQ * 8; e += PY) {
+    float s = 0.f;
+    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + cx) * (NQ * 8) + e];
+    const int q = e >> 3, i = e & 7;
+    atomicAdd(scratch + ((size_t)(blockIdx.x & (kSlots - 1)) * NQ + q) * C + cx * 8 + i, s);
+  }
+}
+
+__global__ __launch_bounds__(kMaxThreads) void bn_stats_kernel(const bf16_t* __restrict__ x, PadGeom g, int c8,
+                                                               int PY, float* __restrict__ scratch) {
+  extern __shared__ float lds[];
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+  for (int p = blockIdx.x * PY + py; p < g.npix; p += gridDim.x * PY) {
+    const u32x4_t v = *(const u32x4_t*)(x + pad_offset(g, p) + cx * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[0][i] += f[i];
+      acc[1][i] += f[i] * f[i];
+    }
+  }
+  block_fold_to_slots<2>(acc, cx, py, c8, PY, g.C, scratch, lds);
+}
+
+// 1 block: fold slots; mode 0 = forward statistics, mode 1 = backward sums
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ scratch, int C, float n,
+                                                          float eps, float momentum,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var,
+                                                          float* __restrict__ save_mean,
+                                                          float* __restrict__ save_rstd) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f, sq = 0.f;
+    for (int k = 0; k < kSlots; ++k) {
+      s += scratch[((size_t)k * 2 + 0) * C + c];
+      sq += scratch[((size_t)k * 2 + 1) * C + c];
+    }
+    const float mean = s / n;
+    float var = sq / n - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    save_mean[c] = mean;
+    save_rstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ scratch, int C,
+                                                              float* __restrict__ dsum,
+                                                              float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < kSlots; ++k) {
+      s0 += scratch[((size_t)k * 2 + 0) * C + c];
+      s1 += scratch[((size_t)k * 2 + 1) * C + c];
+    }
+    dsum[c] = s0;
+    dsum[C + c] = s1;
+    if (dbeta) dbeta[c] += s0;
+    if (dgamma) dgamma[c] += s1;
+  }
+}
+
+template <bool RELU, bool HAS_RES>
+__global__ __launch_bounds__(kMaxThreads) void bn_apply_kernel(const bf16_t* __restrict__ x,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const bf16_t* __restrict__ res, PadGeom g, int c8,
+                                                               int PY, bf16_t* __restrict__ y) {
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = beta[c] - mean[c] * sc[i];
+  }
+  for (int p = blockIdx.x * PY + py; p < g.npix; p += gridDim.x * PY) {
+    const int o = pad_offset(g, p) + cx * 8;
+    float f[8];
+    unpack8(*(const u32x4_t*)(x + o), f);
+    float r[8];
+    if (HAS_RES) unpack8(*(const u32x4_t*)(res + o), r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = f[i] * sc[i] + sh[i];
+      if (HAS_RES) v += r[i];
+      if (RELU) v = v > 0.f ? v : 0.f;
+      f[i] = v;
+    }
+    *(u32x4_t*)(y + o) = pack8(f);
+  }
+}
+
+// backward pass 1.  POOL: gy comes from gpooled[b][c]/(H*W) and the relu mask is recomputed from x.
+template <bool RELU, bool POOL>
+__global__ __launch_bounds__(kMaxThreads) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gy,
+                                                                    const float* __restrict__ gpooled,
+                                                                    const bf16_t* __restrict__ y,
+                                                                    const bf16_t* __restrict__ x,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, PadGeom g,
+                                                                    int c8, int PY, float* __restrict__ scratch) {
+  extern __shared__ float lds[];
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    if (POOL) { ga[i] = gamma[c]; be[i] = beta[c]; }
+  }
+  const float inv_hw = 1.f / (float)(g.H * g.W);
+  const int hw = g.H * g.W;
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+  for (int p = blockIdx.x * PY + py; p < g.npix; p += gridDim.x * PY) {
+    const int o = pad_offset(g, p) + cx * 8;
+    float fx[8], fg[8], fy[8];
+    unpack8(*(const u32x4_t*)(x + o), fx);
+    if (POOL) {
+      const int b = p / hw;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fg[i] = gpooled[(size_t)b * g.C + cx * 8 + i] * inv_hw;
+    } else {
+      unpack8(*(const u32x4_t*)(gy + o), fg);
+      if (RELU) unpack8(*(const u32x4_t*)(y + o), fy);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (fx[i] - mu[i]) * rs[i];
+      float gg = fg[i];
+      if (POOL) gg = (xh * ga[i] + be[i]) > 0.f ? gg : 0.f;
+      else if (RELU) gg = fy[i] > 0.f ? gg : 0.f;
+      acc[0][i] += gg;
+      acc[1][i] += gg * xh;
+    }
+  }
+  block_fold_to_slots<2>(acc, cx, py, c8, PY, g.C, scratch, lds);
+}
+
+template <bool RELU, bool POOL, bool HAS_ADD, bool HAS_GRES>
+__global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ gy, const float* __restrict__ gpooled, const bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ dsum,
+    const bf16_t* __restrict__ gx_add, PadGeom g, int c8, int PY, bf16_t* __restrict__ gx,
+    bf16_t* __restrict__ g_resid) {
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  const float inv_n = 1.f / (float)g.npix;
+  float mu[8], rs[8], ga[8], be[8], k0[8], k1[8], sc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    ga[i] = gamma[c];
+    if (POOL) be[i] = beta[c];
+    sc[i] = ga[i] * rs[i];
+    k0[i] = dsum[c] * inv_n;
+    k1[i] = dsum[g.C + c] * inv_n;
+  }
+  const float inv_hw = 1.f / (float)(g.H * g.W);
+  const int hw = g.H * g.W;
+  for (int p = blockIdx.x * PY + py; p < g.npix; p += gridDim.x * PY) {
+    const int o = pad_offset(g, p) + cx * 8;
+    float fx[8], fg[8], fy[8], fa[8];
+    unpack8(*(const u32x4_t*)(x + o), fx);
+    if (POOL) {
+      const int b = p / hw;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fg[i] = gpooled[(size_t)b * g.C + cx * 8 + i] * inv_hw;
+    } else {
+      unpack8(*(const u32x4_t*)(gy + o), fg);
+      if (RELU) unpack8(*(const u32x4_t*)(y + o), fy);
+    }
+    if (HAS_ADD) unpack8(*(const u32x4_t*)(gx_add + o), fa);
+    float out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (fx[i] - mu[i]) * rs[i];
+      float gg = fg[i];
+      if (POOL) gg = (xh * ga[i] + be[i]) > 0.f ? gg : 0.f;
+      else if (RELU) gg = fy[i] > 0.f ? gg : 0.f;
+      fg[i] = gg;
+      float v = sc[i] * (gg - k0[i] - xh * k1[i]);
+      if (HAS_ADD) v += fa[i];
+      out[i] = v;
+    }
+    *(u32x4_t*)(gx + o) = pack8(out);
+    if (HAS_GRES) *(u32x4_t*)(g_resid + o) = pack8(fg);
+  }
+}
+
+// pooled[b][c] = mean_hw relu(bn(x)); one thread per (b, 8-channel chunk)
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const bf16_t* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, PadGeom g,
+                                                           float* __restrict__ pooled) {
+  const int c8 = g.C / 8;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.B * c8) return;
+  const int b = idx / c8, cx = idx - b * c8;
+  float sc[8], sh[8], acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = beta[c] - mean[c] * sc[i];
+    acc[i] = 0.f;
+  }
+  for (int h = 0; h < g.H; ++h)
+    for (int w = 0; w < g.W; ++w) {
+      float f[8];
+      unpack8(*(const u32x4_t*)(x + (size_t)b * g.img + (h + 1) * g.row + (w + 1) * g.C + cx * 8), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = f[i] * sc[i] + sh[i];
+        acc[i] += v > 0.f ? v : 0.f;
+      }
+    }
+  const float inv = 1.f / (float)(g.H * g.W);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pooled[(size_t)b * g.C + cx * 8 + i] = acc[i] * inv;
+}
+
+// ------------------------------------------------------------------------------------------ host
+
+static int check_shape(int B, int H, int W, int C) {
+  NBDT_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "empty tensor");
+  NBDT_REQUIRE(C % 8 == 0 && C / 8 <= kMaxThreads, "C must be a multiple of 8 and <= 2048");
+  NBDT_REQUIRE((long long)B * (H + 2) * (W + 2) * C < (1ll << 31), "tensor too large for 32-bit offsets");
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
+                             float* running_mean, float* running_var, float* scratch, float* save_mean,
+                             float* save_rstd, void* stream) {
+  NBDT_REQUIRE(x && scratch && save_mean && save_rstd, "null argument");
+  NBDT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must be both set or both NULL");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  NBDT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * kSlots * 2 * C, st));
+  const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st, (const bf16_t*)x, g,
+                     l.c8, l.py, scratch);
+  NBDT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, (float)g.npix, eps, momentum,
+                     running_mean, running_var, save_mean, save_rstd);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                             const float* beta, const void* residual, int32_t relu, int32_t B, int32_t H, int32_t W,
+                             int32_t C, void* y, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && y, "null argument");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  const dim3 grid(grid_for(g, l, 8)), blk(l.threads);
+#define NBDT_APPLY(R, S)                                                                                         \
+  hipLaunchKernelGGL((bn_apply_kernel<R, S>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, \
+                     beta, (const bf16_t*)residual, g, l.c8, l.py, (bf16_t*)y)
+  if (relu) { if (residual) NBDT_APPLY(true, true); else NBDT_APPLY(true, false); }
+  else { if (residual) NBDT_APPLY(false, true); else NBDT_APPLY(false, false); }
+#undef NBDT_APPLY
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float* save_mean,
+                                  const float* save_rstd, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  float* scratch, float* dsum, float* dgamma, float* dbeta, void* stream) {
+  NBDT_REQUIRE(gy && x && save_mean && save_rstd && scratch && dsum, "null argument");
+  NBDT_REQUIRE(!relu || y, "relu backward needs the forward output y");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  NBDT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * kSlots * 2 * C, st));
+  const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
+  const dim3 grid(grid_for(g, l, 16)), blk(l.threads);
+  if (relu)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), grid, blk, shmem, st, (const bf16_t*)gy, nullptr,
+                       (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, nullptr, nullptr, g, l.c8, l.py,
+                       scratch);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), grid, blk, shmem, st, (const bf16_t*)gy, nullptr,
+                       (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, nullptr, nullptr, g, l.c8, l.py,
+                       scratch);
+  NBDT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float* save_mean,
+                                 const float* save_rstd, const float* gamma, const float* dsum, const void* gx_add,
+                                 int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C, void* gx, void* g_resid,
+                                 void* stream) {
+  NBDT_REQUIRE(gy && x && save_mean && save_rstd && gamma && dsum && gx, "null argument");
+  NBDT_REQUIRE(!relu || y, "relu backward needs the forward output y");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  const dim3 grid(grid_for(g, l, 8)), blk(l.threads);
+#define NBDT_BA(R, A, G)                                                                                          \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<R, false, A, G>), grid, blk, 0, st, (const bf16_t*)gy, nullptr,          \
+                     (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, nullptr, dsum,               \
+                     (const bf16_t*)gx_add, g, l.c8, l.py, (bf16_t*)gx, (bf16_t*)g_resid)
+  const bool a = gx_add != nullptr, r = g_resid != nullptr;
+  if (relu) {
+    if (a) { if (r) NBDT_BA(true, true, true); else NBDT_BA(true, true, false); }
+    else { if (r) NBDT_BA(true, false, true); else NBDT_BA(true, false, false); }
+  } else {
+    if (a) { if (r) NBDT_BA(false, true, true); else NBDT_BA(false, true, false); }
+    else { if (r) NBDT_BA(false, false, true); else NBDT_BA(false, false, false); }
+  }
+#undef NBDT_BA
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_relu_pool(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                 const float* beta, int32_t B, int32_t H, int32_t W, int32_t C, float* pooled,
+                                 void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && pooled, "null argument");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  const PadGeom g = make_geom(B, H, W, C);
+  const int n = B * (C / 8);
+  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, pooled);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, const float* save_mean,
+                                       const float* save_rstd, const float* gamma, const float* beta, int32_t B,
+                                       int32_t H, int32_t W, int32_t C, float* scratch, float* dsum, float* dgamma,
+                                       float* dbeta, void* stream) {
+  NBDT_REQUIRE(gpooled && x && save_mean && save_rstd && gamma && beta && scratch && dsum, "null argument");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  NBDT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * kSlots * 2 * C, st));
+  const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st,
+                     nullptr, gpooled, nullptr, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
+                     scratch);
+  NBDT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_pool_bn_bwd_apply(const float* gpooled, const void* x, const float* save_mean,
+                                      const float* save_rstd, const float* gamma, const float* beta,
+                                      const float* dsum, int32_t B, int32_t H, int32_t W, int32_t C, void* gx,
+                                      void* stream) {
+  NBDT_REQUIRE(gpooled && x && save_mean && save_rstd && gamma && beta && dsum && gx, "null argument");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, false, false>), dim3(grid_for(g, l, 8)), dim3(l.threads), 0,
+                     (hipStream_t)stream, nullptr, gpooled, nullptr, (const bf16_t*)x, save_mean, save_rstd, gamma,
+                     beta, dsum, nullptr, g, l.c8, l.py, (bf16_t*)gx, nullptr);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}

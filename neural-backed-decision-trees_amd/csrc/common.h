@@ -47,4 +47,66 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
+// exact n / d for 0 <= n < 2^31 with one mul-hi and one shift (host builds, device divides)
+struct FastDiv {
+  unsigned mul, sh, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) { f.mul = 0; f.sh = 0; return f; }
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;  // s = ceil(log2 d)
+  const unsigned long long num = 1ull << (31 + s);
+  f.mul = (unsigned)((num + d - 1) / d);
+  f.sh = s - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.sh);
+}
+
+// geometry of a padded NHWC activation tensor [B][H+2][W+2][C] (bf16), interior pixels only
+struct PadGeom {
+  int B, H, W, C;
+  int npix;          // B*H*W
+  int row;           // (W+2)*C elements
+  int img;           // (H+2)*(W+2)*C elements
+  FastDiv div_w, div_h;
+};
+inline PadGeom make_geom(int B, int H, int W, int C) {
+  PadGeom g;
+  g.B = B; g.H = H; g.W = W; g.C = C;
+  g.npix = B * H * W;
+  g.row = (W + 2) * C;
+  g.img = (H + 2) * g.row;
+  g.div_w = make_fastdiv((unsigned)W);
+  g.div_h = make_fastdiv((unsigned)H);
+  return g;
+}
+// element offset of channel 0 of interior pixel p (p enumerates (b, h, w) row-major)
+__device__ __forceinline__ int pad_offset(const PadGeom& g, int p) {
+  const unsigned t = fdiv((unsigned)p, g.div_w);
+  const int w = p - (int)t * g.W;
+  const unsigned b = fdiv(t, g.div_h);
+  const int h = (int)t - (int)b * g.H;
+  return (int)b * g.img + (h + 1) * g.row + (w + 1) * g.C;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
 }  // namespace nbdt

@@ -1,0 +1,254 @@
+// Stem convolution, classifier head (nn.Linear) and the SGD update on gfx950.
+//
+//   stem ....... nn.Conv2d(3, 16|64, 3, padding=1) on NCHW fp32 images (reference
+//                nbdt/models/resnet.py:120; pytorchcv CIFARWRN init_block).  K = 27 is far too small
+//                for MFMA and is 0.03% of the step's flops: direct fp32 FMA kernel that also
+//                converts NCHW fp32 -> padded NHWC bf16 on the way out.
+//   linear ..... nn.Linear(640|512, classes) forward/backward (resnet.py:126,148), fp32.
+//   sgd ........ optim.SGD(momentum=0.9, weight_decay=5e-4) (main.py:207) over ONE flat fp32 buffer
+//                holding every parameter; the same pass refreshes the bf16 copy the convs read.
+// All HBM/latency-bound; none is on the MFMA critical path.
+#include "common.h"
+
+using namespace nbdt;
+
+// ------------------------------------------------------------------------------------------ stem
+// thread = (pixel, 8-cout chunk); weights [cout][3][3][3] (co, r, s, ci) staged in LDS
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        int B, int H, int W, int cout, int cpad,
+                                                        bf16_t* __restrict__ out) {
+  extern __shared__ float wl[];  // [cout][27]
+  for (int i = threadIdx.x; i < cout * 27; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const int chunks = cout / 8;
+  const long long total = (long long)B * H * W * chunks;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ck = (int)(idx % chunks);
+  const int p = (int)(idx / chunks);
+  const int x = p % W, y = (p / W) % H, b = p / (W * H);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int r = 0; r < 3; ++r) {
+    const int yy = y + r - 1;
+    if (yy < 0 || yy >= H) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int xx = x + s - 1;
+      if (xx < 0 || xx >= W) continue;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v * wl[(ck * 8 + i) * 27 + (r * 3 + s) * 3 + ci];
+      }
+    }
+  }
+  const size_t o = (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * cpad + ck * 8;
+  *(u32x4_t*)(out + o) = pack8(acc);
+}
+
+// dw[co][27] += sum_pixels gy[pix][co] * img[tap]; block = pixel range, 64-pixel tiles in LDS
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gy,
+                                                         int B, int H, int W, int cout, int cpad, int tiles_per_block,
+                                                         float* __restrict__ dw) {
+  extern __shared__ float lds[];  // gy tile [64][cout] then patch tile [64][27]
+  float* gl = lds;
+  float* pl = lds + 64 * cout;
+  const int npix = B * H * W;
+  const int nout = cout * 27;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // outputs tid, tid+256, ... (<= 2048)
+  for (int t = 0; t < tiles_per_block; ++t) {
+    const int p0 = (blockIdx.x * tiles_per_block + t) * 64;
+    if (p0 >= npix) break;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * cout; i += 256) {
+      const int pp = p0 + i / cout, co = i % cout;
+      float v = 0.f;
+      if (pp < npix) {
+        const int x = pp % W, y = (pp / W) % H, b = pp / (W * H);
+        v = bf16_to_f32(gy[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * cpad + co]);
+      }
+      gl[i] = v;
+    }
+    for (int i = threadIdx.x; i < 64 * 27; i += 256) {
+      const int pp = p0 + i / 27, k = i % 27;
+      float v = 0.f;
+      if (pp < npix) {
+        const int x = pp % W, y = (pp / W) % H, b = pp / (W * H);
+        const int r = k / 9, s = (k / 3) % 3, ci = k % 3;
+        const int yy = y + r - 1, xx = x + s - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
+      }
+      pl[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int o = threadIdx.x + 256 * q;
+      if (o < nout) {
+        const int co = o / 27, k = o % 27;
+        float s = 0.f;
+        for (int pp = 0; pp < 64; ++pp) s += gl[pp * cout + co] * pl[pp * 27 + k];
+        acc[q] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int o = threadIdx.x + 256 * q;
+    if (o < nout) atomicAdd(dw + o, acc[q]);
+  }
+}
+
+extern "C" int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32_t W, int32_t cout_real,
+                              int32_t cpad, void* out, void* stream) {
+  NBDT_REQUIRE(img && w && out, "null argument");
+  NBDT_REQUIRE(B > 0 && H > 0 && W > 0, "empty image batch");
+  NBDT_REQUIRE(cout_real > 0 && cout_real % 8 == 0 && cout_real <= cpad && cpad % 8 == 0, "bad stem channels");
+  const long long total = (long long)B * H * W * (cout_real / 8);
+  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), cout_real * 27 * sizeof(float),
+                     (hipStream_t)stream, img, w, B, H, W, cout_real, cpad, (bf16_t*)out);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int32_t H, int32_t W, int32_t cout_real,
+                               int32_t cpad, float* dw, void* stream) {
+  NBDT_REQUIRE(img && gy && dw, "null argument");
+  NBDT_REQUIRE(cout_real > 0 && cout_real * 27 <= 2048 && cout_real <= cpad, "stem wgrad supports cout <= 75");
+  const int npix = B * H * W;
+  const int tiles = (npix + 63) / 64;
+  int blocks = tiles < 1024 ? tiles : 1024;
+  const int tpb = (tiles + blocks - 1) / blocks;
+  blocks = (tiles + tpb - 1) / tpb;
+  const size_t shmem = (size_t)(64 * cout_real + 64 * 27) * sizeof(float);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, img,
+                     (const bf16_t*)gy, B, H, W, cout_real, cpad, tpb, dw);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ linear
+// one wave per output (b, n): lanes split K, shuffle reduce; rows of x and w are read coalesced
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int B, int K, int N,
+                                                         float* __restrict__ z) {
+  const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (long long)B * N) return;
+  const int b = (int)(o / N), n = (int)(o % N);
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += x[(size_t)b * K + k] * w[(size_t)n * K + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) z[o] = s + (bias ? bias[n] : 0.f);
+}
+
+// gx[b][k] = sum_n gz[b][n] w[n][k]
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ gz, const float* __restrict__ w,
+                                                           int B, int K, int N, float* __restrict__ gx) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * K) return;
+  const int b = (int)(idx / K), k = (int)(idx % K);
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += gz[(size_t)b * N + n] * w[(size_t)n * K + k];
+  gx[idx] = s;
+}
+
+// gw[n][k] += sum_b gz[b][n] x[b][k]; gb[n] += sum_b gz[b][n]; batch split over grid.y with atomics
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ gz, const float* __restrict__ x,
+                                                           int B, int K, int N, int b_per_block,
+                                                           float* __restrict__ gw, float* __restrict__ gb) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * (K + 1)) return;
+  const int n = (int)(idx / (K + 1)), k = (int)(idx % (K + 1));
+  const int b0 = blockIdx.y * b_per_block;
+  const int b1 = b0 + b_per_block < B ? b0 + b_per_block : B;
+  float s = 0.f;
+  if (k < K) {
+    for (int b = b0; b < b1; ++b) s += gz[(size_t)b * N + n] * x[(size_t)b * K + k];
+    atomicAdd(gw + (size_t)n * K + k, s);
+  } else if (gb) {
+    for (int b = b0; b < b1; ++b) s += gz[(size_t)b * N + n];
+    atomicAdd(gb + n, s);
+  }
+}
+
+extern "C" int nbdt_linear_fwd(const float* x, const float* w, const float* b, int32_t B, int32_t K, int32_t N,
+                               float* z, void* stream) {
+  NBDT_REQUIRE(x && w && z && B > 0 && K > 0 && N > 0, "bad linear arguments");
+  const long long outs = (long long)B * N;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, B,
+                     K, N, z);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_linear_bwd(const float* x, const float* w, const float* gz, int32_t B, int32_t K, int32_t N,
+                               float* gx, float* gw, float* gb, void* stream) {
+  NBDT_REQUIRE(x && w && gz && B > 0 && K > 0 && N > 0, "bad linear arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (gx) {
+    const long long n = (long long)B * K;
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gz, w, B, K, N, gx);
+    NBDT_LAUNCH_CHECK();
+  }
+  if (gw) {
+    const long long n = (long long)N * (K + 1);
+    const int splits = B >= 64 ? 16 : 1;
+    const int bpb = (B + splits - 1) / splits;
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((n + 255) / 256), (B + bpb - 1) / bpb), dim3(256), 0, st, gz,
+                       x, B, K, N, bpb, gw, gb);
+    NBDT_LAUNCH_CHECK();
+  }
+  return NBDT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ sgd
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, long long n, float lr, float momentum,
+                                                  float wd, float gscale, bf16_t* __restrict__ pb) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 pv = ((const float4*)p)[i];
+    const float4 gv = ((const float4*)g)[i];
+    float4 bv = ((const float4*)buf)[i];
+    bv.x = momentum * bv.x + (gscale * gv.x + wd * pv.x);
+    bv.y = momentum * bv.y + (gscale * gv.y + wd * pv.y);
+    bv.z = momentum * bv.z + (gscale * gv.z + wd * pv.z);
+    bv.w = momentum * bv.w + (gscale * gv.w + wd * pv.w);
+    pv.x -= lr * bv.x; pv.y -= lr * bv.y; pv.z -= lr * bv.z; pv.w -= lr * bv.w;
+    ((float4*)buf)[i] = bv;
+    ((float4*)p)[i] = pv;
+    if (pb) {
+      uint2 o;
+      o.x = pack_bf16x2(pv.x, pv.y);
+      o.y = pack_bf16x2(pv.z, pv.w);
+      ((uint2*)pb)[i] = o;
+    }
+  }
+  // tail (n % 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float b = momentum * buf[i] + (gscale * g[i] + wd * p[i]);
+    buf[i] = b;
+    p[i] -= lr * b;
+    if (pb) pb[i] = f32_to_bf16(p[i]);
+  }
+}
+
+extern "C" int nbdt_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                             float weight_decay, float grad_scale, void* p_bf16, void* stream) {
+  NBDT_REQUIRE(p && g && buf && n > 0, "bad sgd arguments");
+  NBDT_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0,
+               "flat buffers must be 16-byte aligned");
+  const long long n4 = n >> 2;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long long)n, lr,
+                     momentum, weight_decay, grad_scale, (bf16_t*)p_bf16);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}

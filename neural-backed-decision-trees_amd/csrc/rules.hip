@@ -521,7 +521,7 @@ static int pick_tps(const nbdt_tree* t) { return (t->C > 256 || t->R > 512) ? 25
 
 static int check_common(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz) {
   NBDT_REQUIRE(t != nullptr, "null tree handle");
-  NBDT_REQUIRE(z != nullptr, "null logits");
+  NBDT_REQUIRE(z != nullptr || B == 0, "null logits");
   NBDT_REQUIRE(ztype == NBDT_F32 || ztype == NBDT_BF16 || ztype == NBDT_F16, "unsupported logits dtype");
   NBDT_REQUIRE(B >= 0 && ldz >= t->C, "bad batch / row stride");
   return NBDT_OK;
@@ -531,8 +531,8 @@ extern "C" int nbdt_soft_forward(const nbdt_tree* t, const void* z, int ztype, i
                                  float* P, void* stream) {
   int rc = check_common(t, z, ztype, B, ldz);
   if (rc) return rc;
-  NBDT_REQUIRE(P != nullptr, "null output");
   if (B == 0) return NBDT_OK;
+  NBDT_REQUIRE(P != nullptr, "null output");
   TreeView v = view_of(t);
   NBDT_DISPATCH_RULES(soft_fwd_kernel, t->C + 2 * t->R, v, z, B, ldz, P);
   return NBDT_OK;
@@ -542,8 +542,8 @@ extern "C" int nbdt_soft_backward(const nbdt_tree* t, const void* z, int ztype, 
                                   const float* gP, float* gz, void* stream) {
   int rc = check_common(t, z, ztype, B, ldz);
   if (rc) return rc;
-  NBDT_REQUIRE(gP != nullptr && gz != nullptr, "null gradient buffer");
   if (B == 0) return NBDT_OK;
+  NBDT_REQUIRE(gP != nullptr && gz != nullptr, "null gradient buffer");
   TreeView v = view_of(t);
   NBDT_DISPATCH_RULES(soft_bwd_kernel, 2 * t->C + 2 * t->R, v, z, B, ldz, gP, gz);
   return NBDT_OK;
@@ -570,6 +570,7 @@ extern "C" int nbdt_hard_forward(const nbdt_tree* t, const void* z, int ztype, i
                                  float* path_prob, float* path_entropy, void* stream) {
   int rc = check_common(t, z, ztype, B, ldz);
   if (rc) return rc;
+  if (B == 0) return NBDT_OK;
   NBDT_REQUIRE(pred != nullptr, "null pred");
   const bool any = path_node || path_child || path_prob || path_entropy;
   NBDT_REQUIRE(!any || (path_node && path_child && path_prob && path_entropy),

@@ -66,22 +66,22 @@ SIGNATURES = {
     "nbdt_conv_igemm": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "nbdt_conv_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
     "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
-    "nbdt_bn_stats": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "nbdt_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
-                              c_float, _P, _P, _P, _P, _P, _P]),
-    "nbdt_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_stats": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "nbdt_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                   _P, _P, _P]),
     "nbdt_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
-                                  c_int32, _P, _P, _P, _P, _P]),
+                                  c_int32, _P, _P, _P]),
+    "nbdt_bn_relu_pool": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_pool_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                        _P, _P, _P]),
+    "nbdt_pool_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
+                                       _P]),
     "nbdt_stem_conv": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_stem_wgrad": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "nbdt_bn_relu_pool": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
-                                  _P, _P, _P, _P, _P, _P]),
-    "nbdt_pool_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "nbdt_pool_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32,
-                                       _P, _P, _P, _P]),
     "nbdt_linear_fwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_linear_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
-    "nbdt_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P]),
+    "nbdt_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
 }
 
 

@@ -1,0 +1,441 @@
+"""Backbone execution engine: explicit forward/backward/SGD over hand-written HIP kernels.
+
+This replaces the autograd graph of stock aten/cuDNN ops the reference builds per step
+(main.py:233-239 around nbdt/models/resnet.py:136-149 / pytorchcv CIFARWRN.forward) with a fixed,
+pre-planned launch sequence:
+
+  * every parameter lives in ONE flat fp32 buffer (``ParamStore``) with a flat gradient buffer, a
+    flat momentum buffer and a flat bf16 mirror -- SGD is one kernel, gradient all-reduce is a few
+    large buckets, and the bf16 weights the convs read are refreshed by the SGD kernel itself;
+  * activations are padded NHWC bf16 buffers allocated once per batch size and kept resident
+    (288 GB of HBM: nothing is recomputed or freed inside a step);
+  * forward records nothing: backward is the hand-written mirror sequence.
+
+Python here only sequences C-ABI launches on the current HIP stream (capturable in a hipGraph via
+torch.cuda.CUDAGraph); there is no CPU or PyTorch-op fallback for any tensor op on the path.
+"""
+import math
+
+import torch
+
+from nbdt import ops
+
+ALIGN = 8  # elements: keeps every parameter 16-byte aligned in the bf16 mirror
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class ParamStore:
+    """Flat parameter / gradient / momentum / bf16-mirror buffers + named views."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.entries = {}   # name -> (offset, internal_shape)
+        self.inits = []     # (name, fn(view))
+        self.n = 0
+        self.flat = self.grad = self.mom = self.bf16 = None
+
+    def add(self, name, shape, init):
+        assert self.flat is None and name not in self.entries
+        numel = 1
+        for s in shape:
+            numel *= s
+        self.entries[name] = (self.n, tuple(shape))
+        self.inits.append((name, init))
+        self.n += (numel + ALIGN - 1) // ALIGN * ALIGN
+
+    def finalize(self):
+        n = (self.n + 3) // 4 * 4
+        host = torch.zeros(n, dtype=torch.float32)
+        for name, init in self.inits:
+            off, shape = self.entries[name]
+            numel = math.prod(shape)
+            init(host[off:off + numel].view(shape))
+        self.flat = host.to(self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.mom = torch.zeros_like(self.flat)
+        self.bf16 = self.flat.to(torch.bfloat16)
+
+    def _view(self, buf, name):
+        off, shape = self.entries[name]
+        return buf[off:off + math.prod(shape)].view(shape)
+
+    def p(self, name):
+        return self._view(self.flat, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def pb(self, name):
+        return self._view(self.bf16, name)
+
+    def refresh_bf16(self):
+        self.bf16.copy_(self.flat)   # plumbing: only after load_state_dict, not on the step path
+
+    def zero_grad(self):
+        self.grad.zero_()            # one memset node
+
+
+class Conv:
+    """3x3 / 1x1 convolution (bias-free) with forward, data-gradient and weight-gradient launches."""
+
+    def __init__(self, store, name, cin_real, cout_real, k, stride, gen):
+        self.store, self.name = store, name
+        self.cin_real, self.cout_real, self.k, self.stride = cin_real, cout_real, k, stride
+        self.cin, self.cout = _pad32(cin_real), _pad32(cout_real)
+        self.taps = k * k
+        fan_in = cin_real * k * k
+        bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)   # init.kaiming_uniform_(w), a=0
+
+        def init(v):
+            v.zero_()
+            v[:cout_real, :, :cin_real].uniform_(-bound, bound, generator=gen)
+
+        store.add(name, (self.cout, self.taps, self.cin), init)
+        self._plans = {}
+        self.wd = None
+
+    def logical(self, buf):
+        """[cout_real, cin_real, k, k] view (OIHW semantics, channels_last memory) of a flat buffer."""
+        v = self.store._view(buf, self.name).view(self.cout, self.k, self.k, self.cin)
+        return v[:self.cout_real, :, :, :self.cin_real].permute(0, 3, 1, 2)
+
+    def plan(self, B, Hi, Wi):
+        key = (B, Hi, Wi)
+        if key not in self._plans:
+            self._plans[key] = (
+                ops.conv_fwd_desc(B, Hi, Wi, self.cin, self.cout, self.k, self.stride),
+                ops.conv_dgrad_descs(B, Hi, Wi, self.cin, self.cout, self.k, self.stride, accumulate=False)
+                if not (self.k == 1 and self.stride == 2) else None,
+                ops.conv_dgrad_descs(B, Hi, Wi, self.cin, self.cout, self.k, self.stride, accumulate=True),
+                ops.conv_wgrad_desc(B, Hi, Wi, self.cin, self.cout, self.k, self.stride),
+            )
+        return self._plans[key]
+
+    def refresh_dgrad_weights(self):
+        if self.wd is None:
+            self.wd = torch.empty((self.cin, self.taps, self.cout), dtype=torch.bfloat16,
+                                  device=self.store.device)
+        ops.weight_prep(self.store.p(self.name), self.cout, self.taps, self.cin, None, self.wd)
+
+    def forward(self, x, out, residual=None):
+        B, Hp, Wp, _ = x.shape
+        ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, residual)
+
+    def backward_data(self, gout, gin, accumulate=False):
+        B, Hp, Wp, _ = gin.shape
+        plan = self.plan(B, Hp - 2, Wp - 2)
+        for d in (plan[2] if accumulate else plan[1]):
+            ops.conv_igemm(d, gout, self.wd, gin)
+
+    def backward_weight(self, x, gout):
+        B, Hp, Wp, _ = x.shape
+        ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name))
+
+
+class BatchNorm:
+    def __init__(self, store, name, c_real, scratch_owner):
+        self.store, self.name, self.c_real = store, name, c_real
+        self.C = _pad32(c_real)
+        store.add(name + ".weight", (self.C,), lambda v: v.fill_(1.0))
+        store.add(name + ".bias", (self.C,), lambda v: v.zero_())
+        dev = store.device
+        self.running_mean = torch.zeros(self.C, device=dev)
+        self.running_var = torch.ones(self.C, device=dev)
+        self.num_batches_tracked = torch.zeros((), dtype=torch.long, device=dev)
+        self.mean = torch.empty(self.C, device=dev)
+        self.rstd = torch.empty(self.C, device=dev)
+        self.dsum = torch.empty(2 * self.C, device=dev)
+        self.owner = scratch_owner
+
+    @property
+    def gamma(self):
+        return self.store.p(self.name + ".weight")
+
+    @property
+    def beta(self):
+        return self.store.p(self.name + ".bias")
+
+    def stats(self, x, training):
+        if training:
+            ops.bn_stats(x, self.owner.scratch(self.C), self.mean, self.rstd, self.running_mean,
+                         self.running_var)
+            self.num_batches_tracked += 1
+        else:  # eval: running statistics (two [C]-sized plumbing ops, not on the training path)
+            self.mean.copy_(self.running_mean)
+            torch.rsqrt(self.running_var + ops.BN_EPS, out=self.rstd)
+
+    def apply(self, x, y, relu=True, residual=None):
+        ops.bn_apply(x, self.mean, self.rstd, self.gamma, self.beta, y, relu=relu, residual=residual)
+
+    def backward(self, gy, y, x, gx, relu=True, gx_add=None, g_resid=None):
+        ops.bn_bwd(gy, y, x, self.mean, self.rstd, self.gamma, self.owner.scratch(self.C), self.dsum,
+                   self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, relu=relu,
+                   gx_add=gx_add, g_resid=g_resid)
+
+
+class _Engine:
+    """Shared machinery: parameter store, scratch, activation buffers, optimizer."""
+
+    def __init__(self, device, seed):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the NBDT backbone engine runs on MI355X only (no CPU fallback)")
+        self.store = ParamStore(self.device)
+        self.gen = torch.Generator().manual_seed(seed)
+        self._scratch = None
+        self._bufs = {}
+        self.convs, self.bns = [], []
+        self.training = True
+
+    def scratch(self, C):
+        need = ops.BN_SLOTS * 2 * C
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(max(need, ops.BN_SLOTS * 2 * 2048), device=self.device)
+        return self._scratch
+
+    def buf(self, key, B, H, W, C):
+        k = (key, B, H, W, C)
+        if k not in self._bufs:
+            self._bufs[k] = ops.padded(B, H, W, C, self.device)
+        return self._bufs[k]
+
+    def conv(self, name, cin, cout, k, stride):
+        c = Conv(self.store, name, cin, cout, k, stride, self.gen)
+        self.convs.append(c)
+        return c
+
+    def bn(self, name, c):
+        b = BatchNorm(self.store, name, c, self)
+        self.bns.append(b)
+        return b
+
+    def finalize(self):
+        self.store.finalize()
+        self.refresh_derived_weights()
+
+    def refresh_derived_weights(self):
+        for c in self.convs:
+            c.refresh_dgrad_weights()
+
+    def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
+        """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights."""
+        s = self.store
+        ops.sgd_step(s.flat, s.grad, s.mom, lr, momentum, weight_decay, grad_scale, s.bf16)
+        self.refresh_derived_weights()
+
+    def zero_grad(self):
+        self.store.zero_grad()
+
+    # ---- logical (reference-named) parameter / buffer views for state_dict compatibility
+    def named_params(self, which="flat"):
+        raise NotImplementedError
+
+    def named_buffers(self):
+        raise NotImplementedError
+
+
+class WRNEngine(_Engine):
+    """Pre-activation WideResNet (pytorchcv ``CIFARWRN``: wrn28_10_cifar10/100, reference
+    nbdt/models/wideresnet.py:1-5).  State-dict names follow pytorchcv."""
+
+    def __init__(self, num_classes=10, blocks=28, width_factor=10, in_size=(32, 32), device="cuda", seed=0):
+        super().__init__(device, seed)
+        assert (blocks - 4) % 6 == 0
+        self.num_classes = num_classes
+        self.in_size = in_size
+        layers = [(blocks - 4) // 6] * 3
+        widths = [16 * width_factor, 32 * width_factor, 64 * width_factor]
+        self.stem_c = 16
+        self.stem_cpad = _pad32(16)
+        gen = self.gen
+        bound = math.sqrt(2.0) * math.sqrt(3.0 / 27)
+        self.store.add("features.init_block.weight", (self.stem_c, 3, 3, 3),
+                       lambda v: v.uniform_(-bound, bound, generator=gen))
+        self.units = []
+        cin = 16
+        for i, (n, cout) in enumerate(zip(layers, widths)):
+            for j in range(n):
+                stride = 2 if (j == 0 and i != 0) else 1
+                pre = f"features.stage{i + 1}.unit{j + 1}."
+                u = {
+                    "bn1": self.bn(pre + "body.conv1.bn", cin),
+                    "conv1": self.conv(pre + "body.conv1.conv.weight", cin, cout, 3, stride),
+                    "bn2": self.bn(pre + "body.conv2.bn", cout),
+                    "conv2": self.conv(pre + "body.conv2.conv.weight", cout, cout, 3, 1),
+                    "idconv": (self.conv(pre + "identity_conv.weight", cin, cout, 1, stride)
+                               if (cin != cout or stride != 1) else None),
+                    "cin": cin, "cout": cout, "stride": stride, "key": f"s{i + 1}u{j + 1}",
+                }
+                self.units.append(u)
+                cin = cout
+        self.feat_c = cin
+        self.post_bn = self.bn("features.post_activ.bn", cin)
+        kb = 1.0 / math.sqrt(cin)   # nn.Linear default init
+        self.store.add("output.weight", (num_classes, cin), lambda v: v.uniform_(-kb, kb, generator=gen))
+        self.store.add("output.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
+        self.finalize()
+        self._img = None
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, img, training=None):
+        training = self.training if training is None else training
+        if img.dtype != torch.float32 or not img.is_contiguous():
+            img = img.float().contiguous()
+        B, _, H, W = img.shape
+        self._img, self._B = img, B
+        x = self.buf("x0", B, H, W, self.stem_cpad)
+        ops.stem_conv(img, self.store.p("features.init_block.weight"), x, self.stem_c)
+        h, w = H, W
+        for u in self.units:
+            k, s = u["key"], u["stride"]
+            cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
+            ho, wo = h // s, w // s
+            a1 = self.buf(k + ".a1", B, h, w, cin)
+            t = self.buf(k + ".t", B, ho, wo, cout)
+            a2 = self.buf(k + ".a2", B, ho, wo, cout)
+            out = self.buf(k + ".out", B, ho, wo, cout)
+            u["bn1"].stats(x, training)
+            u["bn1"].apply(x, a1, relu=True)
+            u["conv1"].forward(a1, t)
+            u["bn2"].stats(t, training)
+            u["bn2"].apply(t, a2, relu=True)
+            if u["idconv"] is not None:
+                idn = self.buf(f"idn{cout}", B, ho, wo, cout)
+                u["idconv"].forward(a1, idn)
+                res = idn
+            else:
+                res = x
+            u["conv2"].forward(a2, out, residual=res)
+            u["x_in"], u["x_out"] = x, out
+            x, h, w = out, ho, wo
+        self._x_last, self._hw = x, (h, w)
+        self.post_bn.stats(x, training)
+        self._pooled = self._tensor("pooled", (B, self.feat_c))
+        ops.bn_relu_pool(x, self.post_bn.mean, self.post_bn.rstd, self.post_bn.gamma, self.post_bn.beta,
+                         self._pooled)
+        z = self._tensor("z", (B, self.num_classes))
+        ops.linear_fwd(self._pooled, self.store.p("output.weight"), self.store.p("output.bias"), z)
+        return z
+
+    def _tensor(self, key, shape):
+        k = (key,) + tuple(shape)
+        if k not in self._bufs:
+            self._bufs[k] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return self._bufs[k]
+
+    def backward(self, gz):
+        """Accumulates d(loss)/d(params) into the flat gradient buffer given gz = dloss/dz [B, classes]."""
+        B = self._B
+        gz = gz.contiguous()
+        st = self.store
+        gpool = self._tensor("gpool", (B, self.feat_c))
+        ops.linear_bwd(self._pooled, st.p("output.weight"), gz, gpool, st.g("output.weight"), st.g("output.bias"))
+        h, w = self._hw
+        C = _pad32(self.feat_c)
+        g = self.buf(f"g_out{C}", B, h, w, C)
+        pb = self.post_bn
+        ops.pool_bn_bwd(gpool, self._x_last, pb.mean, pb.rstd, pb.gamma, pb.beta, self.scratch(C), pb.dsum,
+                        st.g(pb.name + ".weight"), st.g(pb.name + ".bias"), g)
+        toggle = 0
+        for u in reversed(self.units):
+            k, s = u["key"], u["stride"]
+            cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
+            ho, wo = h, w
+            hi, wi = ho * s, wo * s
+            a1 = self.buf(k + ".a1", B, hi, wi, cin)
+            t = self.buf(k + ".t", B, ho, wo, cout)
+            a2 = self.buf(k + ".a2", B, ho, wo, cout)
+            ga2 = self.buf(f"ga2_{cout}", B, ho, wo, cout)
+            gt = self.buf(f"gt_{cout}", B, ho, wo, cout)
+            ga1 = self.buf(f"ga1_{cin}_{hi}", B, hi, wi, cin)
+            # ping-pong: the unit's input gradient must not alias its output gradient `g`
+            toggle ^= 1
+            g_in = self.buf(f"g_in{cin}_{hi}_{toggle}", B, hi, wi, cin)
+            u["conv2"].backward_weight(a2, g)
+            u["conv2"].backward_data(g, ga2)
+            u["bn2"].backward(ga2, a2, t, gt, relu=True)
+            u["conv1"].backward_weight(a1, gt)
+            u["conv1"].backward_data(gt, ga1)
+            if u["idconv"] is not None:
+                u["idconv"].backward_weight(a1, g)
+                u["idconv"].backward_data(g, ga1, accumulate=True)
+                u["bn1"].backward(ga1, a1, u["x_in"], g_in, relu=True)
+            else:
+                u["bn1"].backward(ga1, a1, u["x_in"], g_in, relu=True, gx_add=g)
+            g, h, w = g_in, hi, wi
+        ops.stem_wgrad(self._img, g, st.g("features.init_block.weight"), self.stem_c)
+
+    # ------------------------------------------------------------------ reference-named views
+    def named_params(self, which="flat"):
+        buf = {"flat": self.store.flat, "grad": self.store.grad}[which]
+        out = {}
+        out["features.init_block.weight"] = (
+            self.store._view(buf, "features.init_block.weight").permute(0, 3, 1, 2))
+        for c in self.convs:
+            out[c.name] = c.logical(buf)
+        for b in self.bns:
+            out[b.name + ".weight"] = self.store._view(buf, b.name + ".weight")[:b.c_real]
+            out[b.name + ".bias"] = self.store._view(buf, b.name + ".bias")[:b.c_real]
+        out["output.weight"] = self.store._view(buf, "output.weight")
+        out["output.bias"] = self.store._view(buf, "output.bias")
+        return out
+
+    def named_buffers(self):
+        out = {}
+        for b in self.bns:
+            out[b.name + ".running_mean"] = b.running_mean[:b.c_real]
+            out[b.name + ".running_var"] = b.running_var[:b.c_real]
+            out[b.name + ".num_batches_tracked"] = b.num_batches_tracked
+        return out
+
+    def load_state_dict(self, sd):
+        """Copy a pytorchcv-named state dict (fp32 tensors, any device) into the engine."""
+        params, bufs = self.named_params("flat"), self.named_buffers()
+        missing = (set(params) | set(bufs)) - set(sd)
+        missing = {m for m in missing if not m.endswith("num_batches_tracked")}
+        if missing:
+            raise KeyError(f"state dict is missing {sorted(missing)[:5]} ...")
+        for name, view in list(params.items()) + list(bufs.items()):
+            if name in sd:
+                view.copy_(sd[name].to(self.device))
+        self.store.refresh_bf16()
+        self.refresh_derived_weights()
+
+    def state_dict(self):
+        out = {k: v.detach().clone().contiguous() for k, v in self.named_params("flat").items()}
+        out.update({k: v.detach().clone() for k, v in self.named_buffers().items()})
+        return out
+
+
+def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None):
+    """One full training step (main.py:233-239): zero_grad, forward, SoftTreeSupLoss fwd+bwd (one fused
+    kernel), backward, [gradient all-reduce], SGD.  Returns the loss tensor (device scalar)."""
+    engine.zero_grad()
+    z = engine.forward(img, training=True)
+    loss, gz = criterion.loss_and_grad(z, targets)
+    engine.backward(gz)
+    scale = 1.0
+    if comm is not None:
+        comm.all_reduce_grads(engine.store.grad)
+        scale = 1.0 / comm.world_size
+    engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale)
+    return loss
+
+
+def smoke():
+    """Tiny forward+backward+step of the flagship backbone on cuda:0 (called by __graft_entry__)."""
+    import torch.nn as nn
+    from nbdt.loss import SoftTreeSupLoss
+    eng = WRNEngine(num_classes=10, blocks=10, width_factor=2, device="cuda:0", seed=0)
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(8, 3, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 10, (8,), generator=g).cuda()
+    l0 = train_step(eng, crit, img, y, lr=0.05).item()
+    for _ in range(5):
+        l1 = train_step(eng, crit, img, y, lr=0.05).item()
+    assert math.isfinite(l0) and math.isfinite(l1) and l1 < l0, (l0, l1)
+    print(f"smoke ok: WRN-10-2 SoftTreeSupLoss train steps on cuda:0, loss {l0:.4f} -> {l1:.4f}")

@@ -1,0 +1,233 @@
+"""Host-side launch helpers for the backbone kernels of libnbdt_hip.so.
+
+Everything here is plumbing: tensor allocation (PyTorch caching allocator), tap-table construction
+for the implicit-GEMM kernel and raw-pointer hand-off through ctypes.  No arithmetic on the data
+path happens in Python/PyTorch.
+
+Activation layout: padded NHWC bf16 ``[B][H+2][W+2][C]`` with a zero one-pixel border (kernels only
+ever write interiors, so the border stays zero for the lifetime of the buffer).
+Weight layout: ``[cout][taps][cin]`` (fp32 master and bf16 copy); the data-gradient kernel reads
+the transposed, tap-reversed copy ``[cin][taps][cout]`` produced by ``weight_prep``.
+"""
+import ctypes
+
+import torch
+
+from nbdt import _C
+from nbdt._C import ConvDesc, WgradDesc, check, lib, ptr
+
+BN_SLOTS = 32
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def padded(B, H, W, C, device):
+    """Zero-initialised padded NHWC bf16 activation buffer."""
+    return torch.zeros((B, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+
+
+def interior(t):
+    """[B, H, W, C] view of the interior of a padded buffer."""
+    return t[:, 1:-1, 1:-1, :]
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _fill(desc_arr, values):
+    for i, v in enumerate(values):
+        desc_arr[i] = int(v)
+
+
+# ------------------------------------------------------------------------------------------------
+# tap tables
+
+def conv_fwd_desc(B, Hi, Wi, cin, cout, k, stride):
+    """Conv2d(k in {1,3}, padding=k//2, stride) forward: in [B,Hi,Wi,cin] -> out [B,Hi/s,Wi/s,cout]."""
+    assert k in (1, 3) and Hi % stride == 0 and Wi % stride == 0
+    Ho, Wo = Hi // stride, Wi // stride
+    d = ConvDesc()
+    d.B, d.gh, d.gw, d.cin, d.cout = B, Ho, Wo, cin, cout
+    rowi = (Wi + 2) * cin
+    if k == 3:
+        d.ntaps = d.w_ntaps = 9
+        _fill(d.tap_off, [r * rowi + s * cin for r in range(3) for s in range(3)])
+        _fill(d.w_tap, range(9))
+        d.in_base = 0
+    else:
+        d.ntaps = d.w_ntaps = 1
+        d.tap_off[0] = 0
+        d.w_tap[0] = 0
+        d.in_base = rowi + cin
+    d.in_bs, d.in_hs, d.in_ws = (Hi + 2) * rowi, stride * rowi, stride * cin
+    rowo = (Wo + 2) * cout
+    d.out_bs, d.out_hs, d.out_ws, d.out_base = (Ho + 2) * rowo, rowo, cout, rowo + cout
+    d.accumulate = 0
+    return d
+
+
+def conv_dgrad_descs(B, Hi, Wi, cin, cout, k, stride, accumulate=False):
+    """Data gradient of the conv above: g_out [B,Ho,Wo,cout] -> g_in [B,Hi,Wi,cin].
+
+    Returns a list of launches (1 for stride 1; 4 output-parity classes for a strided 3x3).  The
+    weight operand is the tap-reversed transposed copy ``wd[cin][taps][cout]``.
+    """
+    assert k in (1, 3) and stride in (1, 2)
+    Ho, Wo = Hi // stride, Wi // stride
+    rowg = (Wo + 2) * cout          # gradient (kernel input) row, channels = cout
+    rowx = (Wi + 2) * cin           # g_in (kernel output) row, channels = cin
+    out = []
+    if k == 1:
+        d = ConvDesc()
+        d.B, d.gh, d.gw, d.cin, d.cout = B, Ho, Wo, cout, cin
+        d.ntaps = d.w_ntaps = 1
+        d.tap_off[0] = 0
+        d.w_tap[0] = 0
+        d.in_bs, d.in_hs, d.in_ws, d.in_base = (Ho + 2) * rowg, rowg, cout, rowg + cout
+        d.out_bs, d.out_hs, d.out_ws, d.out_base = (Hi + 2) * rowx, stride * rowx, stride * cin, rowx + cin
+        d.accumulate = 1 if accumulate else 0
+        if stride == 2 and not accumulate:
+            raise ValueError("a strided 1x1 dgrad only touches every other pixel: use accumulate=True "
+                             "into a fully written buffer")
+        return [d]
+    if stride == 1:
+        d = ConvDesc()
+        d.B, d.gh, d.gw, d.cin, d.cout = B, Hi, Wi, cout, cin
+        d.ntaps = d.w_ntaps = 9
+        _fill(d.tap_off, [r * rowg + s * cout for r in range(3) for s in range(3)])
+        _fill(d.w_tap, range(9))     # wd is already tap-reversed
+        d.in_bs, d.in_hs, d.in_ws, d.in_base = (Ho + 2) * rowg, rowg, cout, 0
+        d.out_bs, d.out_hs, d.out_ws, d.out_base = (Hi + 2) * rowx, rowx, cin, rowx + cin
+        d.accumulate = 1 if accumulate else 0
+        return [d]
+    # stride 2, 3x3: padded input row hp = 2*ho + r.  hp odd (=2i+1): r=1, ho=i.
+    # hp even (=2i+2): r=0 -> ho=i+1 ; r=2 -> ho=i.  Same for columns.  g rows are padded (+1).
+    taps_1d = {1: [(1, 1)], 0: [(0, 2), (2, 1)]}   # parity -> [(r, padded g row shift)]
+    for ph in (1, 0):
+        for pw in (1, 0):
+            d = ConvDesc()
+            d.B, d.gh, d.gw, d.cin, d.cout = B, Ho, Wo, cout, cin
+            taps = [(r, sr, s, sc) for (r, sr) in taps_1d[ph] for (s, sc) in taps_1d[pw]]
+            d.ntaps, d.w_ntaps = len(taps), 9
+            _fill(d.tap_off, [sr * rowg + sc * cout for (_, sr, _, sc) in taps])
+            _fill(d.w_tap, [8 - (3 * r + s) for (r, _, s, _) in taps])
+            d.in_bs, d.in_hs, d.in_ws, d.in_base = (Ho + 2) * rowg, rowg, cout, 0
+            hp0, wp0 = (1 if ph else 2), (1 if pw else 2)
+            d.out_bs, d.out_hs, d.out_ws = (Hi + 2) * rowx, 2 * rowx, 2 * cin
+            d.out_base = hp0 * rowx + wp0 * cin
+            d.accumulate = 1 if accumulate else 0
+            out.append(d)
+    return out
+
+
+def conv_wgrad_desc(B, Hi, Wi, cin, cout, k, stride):
+    Ho, Wo = Hi // stride, Wi // stride
+    d = WgradDesc()
+    d.B, d.gh, d.gw, d.cin, d.cout = B, Ho, Wo, cin, cout
+    rowi = (Wi + 2) * cin
+    if k == 3:
+        d.ntaps = d.w_ntaps = 9
+        _fill(d.tap_off, [r * rowi + s * cin for r in range(3) for s in range(3)])
+        _fill(d.w_tap, range(9))
+        d.x_base = 0
+    else:
+        d.ntaps = d.w_ntaps = 1
+        d.tap_off[0] = 0
+        d.w_tap[0] = 0
+        d.x_base = rowi + cin
+    d.x_bs, d.x_hs, d.x_ws = (Hi + 2) * rowi, stride * rowi, stride * cin
+    rowo = (Wo + 2) * cout
+    d.g_bs, d.g_hs, d.g_ws, d.g_base = (Ho + 2) * rowo, rowo, cout, rowo + cout
+    return d
+
+
+# ------------------------------------------------------------------------------------------------
+# launches
+
+def conv_igemm(desc, inp, w_bf16, out, residual=None):
+    check(lib().nbdt_conv_igemm(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
+                                stream_ptr(inp.device)))
+
+
+def conv_wgrad(desc, x, gy, dw):
+    check(lib().nbdt_conv_wgrad(ctypes.byref(desc), ptr(x), ptr(gy), ptr(dw), stream_ptr(x.device)))
+
+
+def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):
+    check(lib().nbdt_weight_prep(ptr(w_fp32), cout, taps, cin, ptr(w_bf16), ptr(wd_bf16),
+                                 stream_ptr(w_fp32.device)))
+
+
+def _dims(t):
+    B, Hp, Wp, C = t.shape
+    return B, Hp - 2, Wp - 2, C
+
+
+def bn_stats(x, scratch, save_mean, save_rstd, running_mean=None, running_var=None,
+             eps=BN_EPS, momentum=BN_MOMENTUM):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_stats(ptr(x), B, H, W, C, eps, momentum, ptr(running_mean), ptr(running_var),
+                              ptr(scratch), ptr(save_mean), ptr(save_rstd), stream_ptr(x.device)))
+
+
+def bn_apply(x, mean, rstd, gamma, beta, y, relu=True, residual=None):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual),
+                              1 if relu else 0, B, H, W, C, ptr(y), stream_ptr(x.device)))
+
+
+def bn_bwd(gy, y, x, mean, rstd, gamma, scratch, dsum, dgamma, dbeta, gx, relu=True, gx_add=None,
+           g_resid=None):
+    B, H, W, C = _dims(x)
+    st = stream_ptr(x.device)
+    r = 1 if relu else 0
+    check(lib().nbdt_bn_bwd_reduce(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), r, B, H, W, C,
+                                   ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
+    check(lib().nbdt_bn_bwd_apply(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dsum),
+                                  ptr(gx_add), r, B, H, W, C, ptr(gx), ptr(g_resid), st))
+
+
+def bn_relu_pool(x, mean, rstd, gamma, beta, pooled):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_relu_pool(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, H, W, C,
+                                  ptr(pooled), stream_ptr(x.device)))
+
+
+def pool_bn_bwd(gpooled, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx):
+    B, H, W, C = _dims(x)
+    st = stream_ptr(x.device)
+    check(lib().nbdt_pool_bn_bwd_reduce(ptr(gpooled), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                        B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
+    check(lib().nbdt_pool_bn_bwd_apply(ptr(gpooled), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                       ptr(dsum), B, H, W, C, ptr(gx), st))
+
+
+def stem_conv(img, w, out, cout_real):
+    B, _, H, W = img.shape
+    check(lib().nbdt_stem_conv(ptr(img), ptr(w), B, H, W, cout_real, out.shape[3], ptr(out),
+                               stream_ptr(img.device)))
+
+
+def stem_wgrad(img, gy, dw, cout_real):
+    B, _, H, W = img.shape
+    check(lib().nbdt_stem_wgrad(ptr(img), ptr(gy), B, H, W, cout_real, gy.shape[3], ptr(dw),
+                                stream_ptr(img.device)))
+
+
+def linear_fwd(x, w, b, z):
+    B, K = x.shape
+    N = w.shape[0]
+    check(lib().nbdt_linear_fwd(ptr(x), ptr(w), ptr(b), B, K, N, ptr(z), stream_ptr(x.device)))
+
+
+def linear_bwd(x, w, gz, gx, gw, gb):
+    B, K = x.shape
+    N = w.shape[0]
+    check(lib().nbdt_linear_bwd(ptr(x), ptr(w), ptr(gz), B, K, N, ptr(gx), ptr(gw), ptr(gb),
+                                stream_ptr(x.device)))
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, p_bf16=None):
+    check(lib().nbdt_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, momentum, weight_decay, grad_scale,
+                              ptr(p_bf16), stream_ptr(p.device)))

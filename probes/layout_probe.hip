@@ -53,8 +53,10 @@ __global__ void trread(unsigned short* out /*[64][4]*/, int row_stride_bytes) {
   __syncthreads();
   // natural per-lane address: 16-lane group g reads block g; lane t in group: row t>>2, 8-byte piece t&3
   const int g = l >> 4, t = l & 15;
-  unsigned addr = (unsigned)(size_t)lds;  // LDS byte address (low 32 bits of the generic pointer)
-  addr = (unsigned)(g * 4 * row_stride_bytes + (t >> 2) * row_stride_bytes + (t & 3) * 8);
+  // LDS byte address = low 32 bits of the address_space(3) pointer; derived from `lds` so the
+  // fill above stays live
+  unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)lds;
+  addr += (unsigned)(g * 4 * row_stride_bytes + (t >> 2) * row_stride_bytes + (t & 3) * 8);
   unsigned long long v;
   asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
   for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)(v >> (16 * j));
@@ -122,7 +124,7 @@ int main() {
     bool ok = true;
     for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) {
       int g = l >> 4, t = l & 15;
-      int expect = (g * 4 * stride + j * stride) / 2 + t;
+      int expect = (g * 4 * stride + j * stride) / 2 + t;  // column t of the group's 4x16 block
       if (h[l * 4 + j] != expect) ok = false;
     }
     printf("PROBE tr_b16 hypothesis(column t of 4x16 block): %s\n", ok ? "PASS" : "FAIL");

@@ -1,0 +1,285 @@
+"""Numerics of every backbone HIP kernel (through the C-ABI) against plain PyTorch fp32 references
+of the same op on the same (bf16-rounded) inputs.
+
+Tolerances: conv/BN outputs are stored as bf16 (8 mantissa bits) from fp32 accumulators, so
+|err| <= 2^-8 * |ref| + small absolute slack from accumulation order; fp32 outputs (weight
+gradients, statistics, linear, SGD) are compared at 1e-3 relative (bf16 inputs, fp32 math)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from nbdt import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand_act(B, H, W, C, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16)
+    p = ops.padded(B, H, W, C, DEV)
+    ops.interior(p).copy_(x.to(DEV))
+    return x.float(), p  # fp32 copy of the bf16-rounded values (CPU), padded device buffer
+
+
+def _rand_weight(cout, cin, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+    wb = w.to(torch.bfloat16)
+    internal = wb.float().permute(0, 2, 3, 1).reshape(cout, k * k, cin).contiguous()
+    return wb.float(), internal  # OIHW fp32 of the bf16-rounded values, internal [cout][taps][cin] fp32
+
+
+def _check_border_zero(p):
+    t = p.float()
+    assert t[:, 0].abs().max() == 0 and t[:, -1].abs().max() == 0
+    assert t[:, :, 0].abs().max() == 0 and t[:, :, -1].abs().max() == 0
+
+
+def _close_bf16(got, ref, what):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = 2.0 ** -7 * ref.abs() + 2e-2 * ref.abs().mean() + 1e-6
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {(got - ref).abs().max():.4g}"
+
+
+CONV_CASES = [
+    # B, H, W, cin, cout, k, stride
+    (4, 8, 8, 32, 160, 3, 1),     # NT=5, cin=32 (the padded-stem case)
+    (2, 16, 16, 160, 160, 3, 1),  # WRN stage-1 shape
+    (3, 8, 8, 160, 320, 3, 2),    # strided 3x3 (stage transition), two cout tiles
+    (3, 8, 8, 160, 320, 1, 2),    # strided 1x1 shortcut
+    (2, 8, 8, 64, 128, 3, 1),     # NT=4
+    (2, 8, 8, 64, 64, 3, 1),      # NT=2
+    (5, 4, 4, 96, 32, 1, 1),      # NT=1, M=80 (ragged M tile), 1x1
+    (1, 32, 32, 32, 160, 1, 1),   # 1x1 stride-1 shortcut of WRN unit 1
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,stride", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(B, H, W, cin, cout, k, stride):
+    xf, xp = _rand_act(B, H, W, cin, seed=1)
+    w_oihw, w_int = _rand_weight(cout, cin, k, seed=2)
+    Ho, Wo = H // stride, W // stride
+    w_master = w_int.to(DEV)
+    wb = torch.empty(cout, k * k, cin, dtype=torch.bfloat16, device=DEV)
+    wd = torch.empty(cin, k * k, cout, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w_master, cout, k * k, cin, wb, wd)
+    assert torch.equal(wb.float().cpu(), w_int)
+    assert torch.equal(wd.float().cpu(), w_int.flip(1).permute(2, 1, 0).contiguous())
+
+    # ---- forward (+ residual epilogue)
+    out = ops.padded(B, Ho, Wo, cout, DEV)
+    ops.conv_igemm(ops.conv_fwd_desc(B, H, W, cin, cout, k, stride), xp, wb, out)
+    xt = xf.permute(0, 3, 1, 2).requires_grad_(True)
+    wt = w_oihw.clone().requires_grad_(True)
+    ref = F.conv2d(xt, wt, stride=stride, padding=k // 2)
+    _close_bf16(ops.interior(out), ref.detach().permute(0, 2, 3, 1), "conv fwd")
+    _check_border_zero(out)
+    rf, rp = _rand_act(B, Ho, Wo, cout, seed=3)
+    out2 = ops.padded(B, Ho, Wo, cout, DEV)
+    ops.conv_igemm(ops.conv_fwd_desc(B, H, W, cin, cout, k, stride), xp, wb, out2, residual=rp)
+    _close_bf16(ops.interior(out2), ref.detach().permute(0, 2, 3, 1) + rf, "conv fwd + residual")
+
+    # ---- backward references
+    gf, gp = _rand_act(B, Ho, Wo, cout, seed=4)
+    ref.backward(gf.permute(0, 3, 1, 2))
+    gx_ref = xt.grad.permute(0, 2, 3, 1)
+    gw_ref = wt.grad.permute(0, 2, 3, 1).reshape(cout, k * k, cin)
+
+    # ---- dgrad
+    gx = ops.padded(B, H, W, cin, DEV)
+    if k == 1 and stride == 2:
+        base_f, _ = _rand_act(B, H, W, cin, seed=5)
+        ops.interior(gx).copy_(base_f.to(torch.bfloat16).to(DEV))
+        for d in ops.conv_dgrad_descs(B, H, W, cin, cout, k, stride, accumulate=True):
+            ops.conv_igemm(d, gp, wd, gx)
+        _close_bf16(ops.interior(gx), gx_ref + base_f, "conv dgrad (accumulating strided 1x1)")
+    else:
+        for d in ops.conv_dgrad_descs(B, H, W, cin, cout, k, stride):
+            ops.conv_igemm(d, gp, wd, gx)
+        _close_bf16(ops.interior(gx), gx_ref, "conv dgrad")
+        # accumulate flavour: gx += dgrad
+        for d in ops.conv_dgrad_descs(B, H, W, cin, cout, k, stride, accumulate=True):
+            ops.conv_igemm(d, gp, wd, gx)
+        _close_bf16(ops.interior(gx), 2 * gx_ref, "conv dgrad accumulate")
+    _check_border_zero(gx)
+
+    # ---- wgrad (fp32, += semantics)
+    dw = torch.zeros(cout, k * k, cin, dtype=torch.float32, device=DEV)
+    wdsc = ops.conv_wgrad_desc(B, H, W, cin, cout, k, stride)
+    ops.conv_wgrad(wdsc, xp, gp, dw)
+    np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), rtol=2e-3, atol=2e-3 * gw_ref.abs().mean().item())
+    ops.conv_wgrad(wdsc, xp, gp, dw)
+    np.testing.assert_allclose(dw.cpu().numpy(), 2 * gw_ref.numpy(), rtol=2e-3, atol=4e-3 * gw_ref.abs().mean().item())
+
+
+def test_conv_identity_weights_are_transpose_detecting():
+    # w[co][center][ci] = 1 if co == perm(ci): output channel co must equal input channel perm^-1(co)
+    B, H, W, C = 2, 8, 8, 160
+    xf, xp = _rand_act(B, H, W, C, seed=7)
+    perm = torch.randperm(C, generator=torch.Generator().manual_seed(1))
+    w = torch.zeros(C, 9, C)
+    w[perm, 4, torch.arange(C)] = 1.0
+    wb = w.to(torch.bfloat16).to(DEV)
+    out = ops.padded(B, H, W, C, DEV)
+    ops.conv_igemm(ops.conv_fwd_desc(B, H, W, C, C, 3, 1), xp, wb, out)
+    got = ops.interior(out).float().cpu()
+    exp = torch.zeros_like(xf)
+    exp[..., perm] = xf
+    assert torch.equal(got, exp)
+    # shifted tap: w at tap (r=0,s=2) moves the image down-left by one pixel
+    w2 = torch.zeros(C, 9, C)
+    w2[torch.arange(C), 2, torch.arange(C)] = 1.0
+    ops.conv_igemm(ops.conv_fwd_desc(B, H, W, C, C, 3, 1), xp, w2.to(torch.bfloat16).to(DEV), out)
+    got = ops.interior(out).float().cpu()
+    exp = torch.zeros_like(xf)
+    exp[:, 1:, :-1] = xf[:, :-1, 1:]
+    assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(4, 8, 8, 160), (3, 16, 16, 32), (2, 8, 8, 640), (5, 4, 4, 64)])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (False, True), (True, True)])
+def test_batchnorm_forward_backward(B, H, W, C, relu, with_res):
+    xf, xp = _rand_act(B, H, W, C, seed=11, scale=2.0)
+    xf = xf + 0.5
+    ops.interior(xp).copy_(xf.to(torch.bfloat16).to(DEV))
+    xf = ops.interior(xp).float().cpu()
+    g = torch.Generator().manual_seed(12)
+    gamma = (torch.rand(C, generator=g) + 0.5)
+    beta = torch.randn(C, generator=g) * 0.3
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rf, rp = _rand_act(B, H, W, C, seed=13) if with_res else (None, None)
+
+    scratch = torch.empty(ops.BN_SLOTS * 2 * C, device=DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    ops.bn_stats(xp, scratch, mean, rstd, rm, rv)
+    y = ops.padded(B, H, W, C, DEV)
+    ops.bn_apply(xp, mean, rstd, gamma.to(DEV), beta.to(DEV), y, relu=relu, residual=rp)
+
+    xt = xf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rmr, rvr = rm0.clone(), rv0.clone()
+    ref = F.batch_norm(xt, rmr, rvr, gt, bt, training=True, momentum=0.1, eps=1e-5)
+    rt = None
+    if with_res:
+        rt = rf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        ref = ref + rt
+    if relu:
+        ref = F.relu(ref)
+    np.testing.assert_allclose(mean.cpu().numpy(), xf.mean((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (xf.var((0, 1, 2), unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(rm.cpu().numpy(), rmr.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), rvr.numpy(), rtol=1e-4, atol=1e-5)
+    _close_bf16(ops.interior(y), ref.detach().permute(0, 2, 3, 1), "bn apply")
+    _check_border_zero(y)
+
+    # backward.  The HIP path masks with the stored bf16 y; use the same mask in the reference by
+    # differentiating through the reference output (identical except exactly-at-zero roundings).
+    gf, gp = _rand_act(B, H, W, C, seed=14)
+    ref.backward(gf.permute(0, 3, 1, 2))
+    dsum = torch.empty(2 * C, device=DEV)
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx = ops.padded(B, H, W, C, DEV)
+    gres = ops.padded(B, H, W, C, DEV) if with_res else None
+    af, ap = _rand_act(B, H, W, C, seed=15)
+    ops.bn_bwd(gp, y, xp, mean, rstd, gamma.to(DEV), scratch, dsum, dgamma, dbeta, gx, relu=relu, gx_add=ap,
+               g_resid=gres)
+    # y values that round to exactly 0 in bf16 but are >0 in fp32 flip the mask for a few elements
+    gx_ref = xt.grad.permute(0, 2, 3, 1) + af
+    got = ops.interior(gx).float().cpu()
+    tol = 2.0 ** -7 * gx_ref.abs() + 3e-2 * gx_ref.abs().mean()
+    frac_bad = ((got - gx_ref).abs() > tol).float().mean().item()
+    assert frac_bad < 2e-3, f"bn bwd gx: {frac_bad:.4%} elements off"
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gt.grad.numpy(), rtol=2e-2, atol=2e-2 * gt.grad.abs().mean().item())
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bt.grad.numpy(), rtol=2e-2, atol=2e-2 * bt.grad.abs().mean().item())
+    if with_res:
+        gr = ops.interior(gres).float().cpu()
+        gr_ref = rt.grad.permute(0, 2, 3, 1)
+        assert ((gr - gr_ref).abs() > 2.0 ** -7 * gr_ref.abs() + 1e-3).float().mean().item() < 2e-3
+    _check_border_zero(gx)
+
+
+def test_head_pool_linear():
+    B, H, W, C, N = 6, 8, 8, 640, 10
+    xf, xp = _rand_act(B, H, W, C, seed=21)
+    g = torch.Generator().manual_seed(22)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    w, b = torch.randn(N, C, generator=g) / C ** 0.5, torch.randn(N, generator=g) * 0.1
+    scratch = torch.empty(ops.BN_SLOTS * 2 * C, device=DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_stats(xp, scratch, mean, rstd)
+    pooled = torch.empty(B, C, device=DEV)
+    ops.bn_relu_pool(xp, mean, rstd, gamma.to(DEV), beta.to(DEV), pooled)
+    z = torch.empty(B, N, device=DEV)
+    ops.linear_fwd(pooled, w.to(DEV), b.to(DEV), z)
+
+    xt = xf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    wt, bbt = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    a = F.relu(F.batch_norm(xt, None, None, gt, bt, training=True, eps=1e-5))
+    pr = F.avg_pool2d(a, (H, W)).flatten(1)
+    pr.retain_grad()
+    zr = F.linear(pr, wt, bbt)
+    np.testing.assert_allclose(pooled.cpu().numpy(), pr.detach().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(z.cpu().numpy(), zr.detach().numpy(), rtol=1e-3, atol=1e-4)
+
+    gz = torch.randn(B, N, generator=g)
+    zr.backward(gz)
+    gpool = torch.empty(B, C, device=DEV)
+    gw, gb = torch.zeros(N, C, device=DEV), torch.zeros(N, device=DEV)
+    ops.linear_bwd(pooled, w.to(DEV), gz.to(DEV), gpool, gw, gb)
+    np.testing.assert_allclose(gpool.cpu().numpy(), pr.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gw.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(gb.cpu().numpy(), bbt.grad.numpy(), rtol=1e-3, atol=1e-5)
+    dsum = torch.empty(2 * C, device=DEV)
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx = ops.padded(B, H, W, C, DEV)
+    ops.pool_bn_bwd(gpool, xp, mean, rstd, gamma.to(DEV), beta.to(DEV), scratch, dsum, dgamma, dbeta, gx)
+    gx_ref = xt.grad.permute(0, 2, 3, 1)
+    got = ops.interior(gx).float().cpu()
+    tol = 2.0 ** -7 * gx_ref.abs() + 3e-2 * gx_ref.abs().mean()
+    assert ((got - gx_ref).abs() > tol).float().mean().item() < 2e-3
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gt.grad.numpy(), rtol=1e-2, atol=1e-2 * gt.grad.abs().mean().item())
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bt.grad.numpy(), rtol=1e-2, atol=1e-2 * bt.grad.abs().mean().item())
+
+
+@pytest.mark.parametrize("cout,cpad", [(16, 32), (64, 64)])
+def test_stem(cout, cpad):
+    B, H, W = 3, 16, 16
+    g = torch.Generator().manual_seed(31)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(cout, 3, 3, 3, generator=g) / 27 ** 0.5          # OIHW
+    w_int = w.permute(0, 2, 3, 1).contiguous()                       # (co, r, s, ci)
+    out = ops.padded(B, H, W, cpad, DEV)
+    ops.stem_conv(img.to(DEV), w_int.to(DEV), out, cout)
+    wt = w.clone().requires_grad_(True)
+    ref = F.conv2d(img, wt, padding=1)
+    _close_bf16(ops.interior(out)[..., :cout], ref.detach().permute(0, 2, 3, 1), "stem conv")
+    assert ops.interior(out)[..., cout:].abs().max().item() == 0 if cpad > cout else True
+    gf, gp = _rand_act(B, H, W, cpad, seed=32)
+    ref.backward(gf[..., :cout].permute(0, 3, 1, 2))
+    dw = torch.zeros(cout, 27, device=DEV)
+    ops.stem_wgrad(img.to(DEV), gp, dw, cout)
+    np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.permute(0, 2, 3, 1).reshape(cout, 27).numpy(),
+                               rtol=1e-3, atol=1e-3)
+
+
+def test_sgd_matches_torch_optim():
+    n = 100003
+    g = torch.Generator().manual_seed(41)
+    p0, g0 = torch.randn(n + 1, generator=g)[:n].clone(), torch.randn(n, generator=g)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    pd, buf = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(3):
+        grad = g0 * (step + 1)
+        p.grad = grad.clone()
+        opt.step()
+        ops.sgd_step(pd, grad.to(DEV), buf, 0.1, 0.9, 5e-4, 1.0, pb)
+    np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(pb.cpu(), pd.cpu().to(torch.bfloat16))

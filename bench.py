@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec training SoftNBDT WideResNet-28-10 on CIFAR10-shaped synthetic
+batches (BASELINE.json `metric`, configs[1]: batch 512 per MI355X, fused rules/loss kernel).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+A "step" = zero_grad -> backbone forward -> SoftTreeSupLoss forward+backward (one fused kernel) ->
+backbone backward -> [RCCL all-reduce of gradients, overlapped] -> SGD(momentum .9, wd 5e-4) on one
+batch already resident in HBM.  Weak scaling: 512 images per GPU.  Prints ONE JSON line on rank 0.
+
+roofline: the dominant kernel is conv_igemm (forward + data-gradient implicit GEMMs; 2/3 of the
+step's flops).  achieved = algorithmic flops of its launches / their HIP-event durations, measured
+live over the timed steps on the launch stream; peak = 2.5 PFLOP/s dense bf16 MFMA (gfx950).
+cpu_baseline: the fp32 CPU oracle port (oracle/torch_models.py WRN + oracle/nbdt_oracle.py loss) on a
+bounded sample, all host cores -- test infrastructure used only as the timed baseline here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import nbdt_path  # noqa: E402
+
+nbdt_path.add()
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0
+GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
+
+
+def cpu_baseline(batch, num_classes):
+    """fp32 CPU oracle port timed on this box's host cores: one warm-up step at batch 8, one timed
+    step at `batch` images (bounded sample of the same workload)."""
+    nbdt_path.add(oracle=True)
+    import nbdt_oracle as O
+    import torch_models as TM
+    torch.manual_seed(0)
+    threads = torch.get_num_threads()
+    net = TM.WRN(num_classes, 28, 10)
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10",
+                                          os.path.join(nbdt_path.PKG_DIR, "nbdt")))
+
+    def step(b):
+        x = torch.randn(b, 3, 32, 32)
+        y = torch.randint(0, num_classes, (b,))
+        opt.zero_grad()
+        z = net(x)
+        _, dz = O.soft_tree_sup_loss(otree, z.detach().numpy(), y.numpy())
+        z.backward(torch.from_numpy(dz))
+        opt.step()
+
+    step(8)
+    t0 = time.perf_counter()
+    step(batch)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 training step of fp32 torch-CPU WRN-28-10 + oracle SoftTreeSupLoss at batch {batch} "
+                      f"({dt:.1f} s), after a batch-8 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling)")
+    ap.add_argument("--classes", type=int, default=10)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from nbdt import dist as ndist
+    from nbdt import engine as E
+    from nbdt import ops
+    from nbdt.loss import SoftTreeSupLoss
+
+    rank, world, local = ndist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    comm = ndist.GradComm() if world > 1 else None
+
+    eng = E.WRNEngine(num_classes=args.classes, blocks=28, width_factor=10, device=dev, seed=0)
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
+    y = torch.randint(0, args.classes, (args.batch,), generator=g).to(dev)
+    lr = 0.01
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        E.train_step(eng, crit, img, y, lr, comm=comm)
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    sync()
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = E.train_step(eng, crit, img, y, lr, comm=comm)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+    loss_val = loss.item()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+
+    ms = 1e3 * dt / args.steps
+    value = args.batch * world * args.steps / dt
+    out = {
+        "metric": "images/sec training SoftNBDT WRN28x10 CIFAR10",
+        "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "WideResNet-28-10 + SoftTreeSupLoss (induced-wrn28_10_cifar10, 10 leaves), "
+                               "CIFAR10-shaped 3x32x32, SGD m=0.9 wd=5e-4",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "final_loss": round(loss_val, 4)},
+        "step_mfma_frac": round(value / world * GFLOP_PER_IMG_TRAIN / 1e3 / PEAK_BF16_TFLOPS, 4),
+    }
+    if timer is not None:
+        summ = timer.summary()
+        k = summ.get("conv_igemm")
+        if k:
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad implicit GEMM)",
+                               "achieved": round(k["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "avg_launch_us": round(k["avg_us"], 1),
+                               "launches_per_step": k["launches"] // args.steps,
+                               "flops_per_launch_avg": k["flops"] / k["launches"]}
+        w = summ.get("conv_wgrad")
+        if w:
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv_wgrad_kernel", "achieved": round(w["tflops"], 1),
+                                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(w["tflops"] / PEAK_BF16_TFLOPS, 4),
+                                     "avg_launch_us": round(w["avg_us"], 1),
+                                     "launches_per_step": w["launches"] // args.steps}
+            out["step_ms_in_mfma_kernels"] = round((k["ms"] + w["ms"]) / args.steps, 3) if k else None
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.classes)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI.
+
+Replaces ``torch.nn.DataParallel`` (reference main.py:160-162: replicate / scatter / gather /
+reduce-to-GPU-0 every step).  Here each rank owns a full replica, runs the loss on its own shard of
+the minibatch (like the reference's DDP example, examples/imagenet/losses/nbdt_losses.py:6-21), and
+the ONLY exchange is a sum all-reduce of the flat fp32 gradient buffer, issued per stage-sized
+bucket on a side stream as soon as backward has produced it, so it overlaps the remaining
+backward kernels.  The 1/world_size averaging is folded into the SGD kernel (``grad_scale``).
+
+BatchNorm statistics stay per-rank, exactly like DataParallel's per-replica BN (no SyncBN in the
+reference).  With the ``gloo`` backend and CPU tensors the same class runs in the unit tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world_size, local_rank); a single process without those variables is (0, 1, 0)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_batch(t, rank, world):
+    """Rank's contiguous shard of a global batch along dim 0 (global batch must divide evenly)."""
+    n = t.shape[0]
+    if n % world != 0:
+        raise ValueError(f"global batch {n} is not divisible by world size {world}")
+    per = n // world
+    return t[rank * per:(rank + 1) * per]
+
+
+class GradComm:
+    """Bucketed, overlapped sum all-reduce of a flat gradient buffer."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._stream = None
+        self._work = []
+
+    def reduce_range(self, flat, lo, hi):
+        """Launch the all-reduce of flat[lo:hi]; everything already enqueued on the current stream
+        that wrote this range is ordered before it."""
+        if self.world_size == 1 or hi <= lo:
+            return
+        view = flat[lo:hi]
+        if flat.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(ev)
+                self._work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self, flat=None):
+        """Order every outstanding all-reduce before subsequent work on the current stream."""
+        for w in self._work:
+            w.wait()
+        self._work = []
+        if self._stream is not None and flat is not None and flat.is_cuda:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+
+    def all_reduce_grads(self, flat, buckets=None):
+        """Whole-buffer convenience form (used when backward did not stream buckets itself)."""
+        if self.world_size == 1:
+            return
+        for lo, hi in (buckets or [(0, flat.numel())]):
+            self.reduce_range(flat, lo, hi)
+        self.finish(flat)

@@ -144,7 +144,7 @@ class BatchNorm:
         dev = store.device
         self.running_mean = torch.zeros(self.C, device=dev)
         self.running_var = torch.ones(self.C, device=dev)
-        self.num_batches_tracked = torch.zeros((), dtype=torch.long, device=dev)
+        self.num_batches_tracked = 0   # host counter (state_dict compat); no launch on the step path
         self.mean = torch.empty(self.C, device=dev)
         self.rstd = torch.empty(self.C, device=dev)
         self.dsum = torch.empty(2 * self.C, device=dev)
@@ -189,6 +189,7 @@ class _Engine:
         self._bufs = {}
         self.convs, self.bns = [], []
         self.training = True
+        self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
 
     def scratch(self, C):
         need = ops.BN_SLOTS * 2 * C
@@ -326,9 +327,19 @@ class WRNEngine(_Engine):
             self._bufs[k] = torch.empty(shape, dtype=torch.float32, device=self.device)
         return self._bufs[k]
 
-    def backward(self, gz):
-        """Accumulates d(loss)/d(params) into the flat gradient buffer given gz = dloss/dz [B, classes]."""
+    def grad_buckets(self):
+        """(lo, hi) ranges of the flat gradient buffer in the order backward completes them:
+        [stage3 .. classifier], [stage2], [stem .. stage1]."""
+        ent = self.store.entries
+        s2 = ent["features.stage2.unit1.body.conv1.bn.weight"][0]
+        s3 = ent["features.stage3.unit1.body.conv1.bn.weight"][0]
+        return [(s3, self.store.grad.numel()), (s2, s3), (0, s2)]
+
+    def backward(self, gz, comm=None):
+        """Accumulates d(loss)/d(params) into the flat gradient buffer given gz = dloss/dz [B, classes].
+        With a GradComm, each stage's gradient bucket is all-reduced as soon as it is complete."""
         B = self._B
+        buckets = self.grad_buckets() if comm is not None else None
         gz = gz.contiguous()
         st = self.store
         gpool = self._tensor("gpool", (B, self.feat_c))
@@ -348,12 +359,14 @@ class WRNEngine(_Engine):
             a1 = self.buf(k + ".a1", B, hi, wi, cin)
             t = self.buf(k + ".t", B, ho, wo, cout)
             a2 = self.buf(k + ".a2", B, ho, wo, cout)
-            ga2 = self.buf(f"ga2_{cout}", B, ho, wo, cout)
-            gt = self.buf(f"gt_{cout}", B, ho, wo, cout)
-            ga1 = self.buf(f"ga1_{cin}_{hi}", B, hi, wi, cin)
+            tag = ("@" + k) if self.debug_keep else ""
+            ga2 = self.buf(f"ga2_{cout}{tag}", B, ho, wo, cout)
+            gt = self.buf(f"gt_{cout}{tag}", B, ho, wo, cout)
+            ga1 = self.buf(f"ga1_{cin}_{hi}{tag}", B, hi, wi, cin)
             # ping-pong: the unit's input gradient must not alias its output gradient `g`
             toggle ^= 1
-            g_in = self.buf(f"g_in{cin}_{hi}_{toggle}", B, hi, wi, cin)
+            g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
+            u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             u["conv2"].backward_weight(a2, g)
             u["conv2"].backward_data(g, ga2)
             u["bn2"].backward(ga2, a2, t, gt, relu=True)
@@ -366,7 +379,12 @@ class WRNEngine(_Engine):
             else:
                 u["bn1"].backward(ga1, a1, u["x_in"], g_in, relu=True, gx_add=g)
             g, h, w = g_in, hi, wi
+            if comm is not None and u["key"] in ("s3u1", "s2u1"):
+                comm.reduce_range(st.grad, *buckets[0 if u["key"] == "s3u1" else 1])
         ops.stem_wgrad(self._img, g, st.g("features.init_block.weight"), self.stem_c)
+        if comm is not None:
+            comm.reduce_range(st.grad, *buckets[2])
+            comm.finish(st.grad)
 
     # ------------------------------------------------------------------ reference-named views
     def named_params(self, which="flat"):
@@ -388,7 +406,7 @@ class WRNEngine(_Engine):
         for b in self.bns:
             out[b.name + ".running_mean"] = b.running_mean[:b.c_real]
             out[b.name + ".running_var"] = b.running_var[:b.c_real]
-            out[b.name + ".num_batches_tracked"] = b.num_batches_tracked
+            out[b.name + ".num_batches_tracked"] = torch.tensor(b.num_batches_tracked, dtype=torch.long)
         return out
 
     def load_state_dict(self, sd):
@@ -399,8 +417,11 @@ class WRNEngine(_Engine):
         if missing:
             raise KeyError(f"state dict is missing {sorted(missing)[:5]} ...")
         for name, view in list(params.items()) + list(bufs.items()):
-            if name in sd:
+            if name in sd and not name.endswith("num_batches_tracked"):
                 view.copy_(sd[name].to(self.device))
+        for b in self.bns:
+            if b.name + ".num_batches_tracked" in sd:
+                b.num_batches_tracked = int(sd[b.name + ".num_batches_tracked"])
         self.store.refresh_bf16()
         self.refresh_derived_weights()
 
@@ -416,11 +437,8 @@ def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5
     engine.zero_grad()
     z = engine.forward(img, training=True)
     loss, gz = criterion.loss_and_grad(z, targets)
-    engine.backward(gz)
-    scale = 1.0
-    if comm is not None:
-        comm.all_reduce_grads(engine.store.grad)
-        scale = 1.0 / comm.world_size
+    engine.backward(gz, comm=comm)
+    scale = 1.0 / comm.world_size if comm is not None else 1.0
     engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale)
     return loss
 

@@ -143,15 +143,67 @@ def conv_wgrad_desc(B, Hi, Wi, cin, cout, k, stride):
 
 
 # ------------------------------------------------------------------------------------------------
+# optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py)
+
+class KernelTimer:
+    """Brackets every conv_igemm / conv_wgrad launch with HIP events on the stream the kernel is
+    launched on (torch's current stream) and accumulates algorithmic flops per kernel family."""
+
+    def __init__(self):
+        self.items = []   # (kind, flops, start_event, end_event)
+
+    def bracket(self, kind, flops, device):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        self.items.append((kind, flops, s, e))
+        return s, e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, s, e in self.items:
+            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += s.elapsed_time(e)
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["ms"] / max(d["launches"], 1)
+            d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+# ------------------------------------------------------------------------------------------------
 # launches
 
 def conv_igemm(desc, inp, w_bf16, out, residual=None):
+    ev = None
+    if _timer is not None:
+        flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
+        ev = _timer.bracket("conv_igemm", flops, inp.device)
+        ev[0].record()
     check(lib().nbdt_conv_igemm(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
                                 stream_ptr(inp.device)))
+    if ev is not None:
+        ev[1].record()
 
 
 def conv_wgrad(desc, x, gy, dw):
+    ev = None
+    if _timer is not None:
+        flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
+        ev = _timer.bracket("conv_wgrad", flops, x.device)
+        ev[0].record()
     check(lib().nbdt_conv_wgrad(ctypes.byref(desc), ptr(x), ptr(gy), ptr(dw), stream_ptr(x.device)))
+    if ev is not None:
+        ev[1].record()
 
 
 def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):

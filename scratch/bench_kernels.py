@@ -1,0 +1,43 @@
+"""Micro-benchmark of the MFMA kernels at the WRN-28-10 B=512 shapes (HIP-event timing)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nbdt_path; nbdt_path.add()
+import torch
+from nbdt import ops
+DEV = 'cuda:0'
+B = int(os.environ.get('B', 512))
+which = os.environ.get('WHICH', 'wgrad,fwd,dgrad').split(',')
+reps = int(os.environ.get('REPS', 5))
+shapes = [(32, 160, 160, 3, 1), (16, 320, 320, 3, 1), (8, 640, 640, 3, 1), (32, 160, 320, 3, 2), (32, 32, 160, 3, 1)]
+if os.environ.get('SHAPES'):
+    shapes = [shapes[int(i)] for i in os.environ['SHAPES'].split(',')]
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+for (H, cin, cout, k, st) in shapes:
+    Ho = H // st
+    x = ops.padded(B, H, H, cin, DEV); ops.interior(x).normal_()
+    g = ops.padded(B, Ho, Ho, cout, DEV); ops.interior(g).normal_()
+    w = (torch.randn(cout, k * k, cin, device=DEV) * 0.05)
+    wb = w.to(torch.bfloat16); wd = torch.empty(cin, k * k, cout, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w, cout, k * k, cin, None, wd)
+    out = ops.padded(B, Ho, Ho, cout, DEV); gx = ops.padded(B, H, H, cin, DEV)
+    dw = torch.zeros(cout, k * k, cin, device=DEV)
+    flops = 2.0 * B * Ho * Ho * cout * cin * k * k
+    line = f"H={H} {cin}->{cout} k{k} s{st}: "
+    if 'fwd' in which:
+        d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
+        t = timeit(lambda: ops.conv_igemm(d, x, wb, out)); line += f"fwd {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
+    if 'dgrad' in which:
+        ds = ops.conv_dgrad_descs(B, H, H, cin, cout, k, st)
+        t = timeit(lambda: [ops.conv_igemm(d, g, wd, gx) for d in ds]); line += f"dgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
+    if 'wgrad' in which:
+        d = ops.conv_wgrad_desc(B, H, H, cin, cout, k, st)
+        t = timeit(lambda: ops.conv_wgrad(d, x, g, dw)); line += f"wgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF"
+    print(line, flush=True)

@@ -1,0 +1,66 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/nbdt_hip.h
+declares (no compute calls without a GPU); the product path refuses CPU tensors loudly."""
+import os
+import re
+
+import pytest
+import torch
+
+import nbdt_path
+from nbdt import _C
+
+
+def _header_symbols():
+    text = open(os.path.join(nbdt_path.ROOT, "include", "nbdt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbdt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_C.libpath()):
+        from nbdt import _build
+        _build.build()
+    declared = _header_symbols()
+    assert len(declared) >= 26
+    assert sorted(_C.SIGNATURES) == declared, "ctypes table and header disagree"
+    exported = set(_C.exported_symbols())
+    assert not (set(declared) - exported), f"missing from .so: {sorted(set(declared) - exported)}"
+    lib = _C.lib()
+    assert lib.nbdt_version() >= 100
+    assert isinstance(lib.nbdt_last_error(), bytes)
+    assert lib.nbdt_device_count() >= 0
+
+
+def test_argument_validation_without_gpu():
+    lib = _C.lib()
+    # null handle / null pointers are rejected before any HIP call
+    assert lib.nbdt_soft_forward(None, None, 0, 4, 10, None, None) == -1
+    assert b"null tree handle" in lib.nbdt_last_error()
+    d = _C.ConvDesc()
+    assert lib.nbdt_conv_igemm(d, None, None, None, None, None) == -1
+
+
+def test_product_path_refuses_cpu_tensors():
+    from nbdt.loss import SoftTreeSupLoss
+    from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules
+    z = torch.randn(4, 10)
+    with pytest.raises(_C.NBDTHipError):
+        SoftEmbeddedDecisionRules(dataset="CIFAR10", hierarchy="induced")(z)
+    with pytest.raises(_C.NBDTHipError):
+        HardEmbeddedDecisionRules(dataset="CIFAR10", hierarchy="induced")(z)
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=torch.nn.CrossEntropyLoss(), hierarchy="induced")
+    with pytest.raises(_C.NBDTHipError):
+        crit(z, torch.zeros(4, dtype=torch.long))
+    if not torch.cuda.is_available():
+        from nbdt import engine
+        with pytest.raises(RuntimeError):
+            engine.WRNEngine(device="cpu")
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(nbdt_path.PKG_DIR, "nbdt")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "nbdt_oracle" not in src and "torch_models" not in src, f

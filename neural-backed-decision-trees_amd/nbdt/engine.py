@@ -81,13 +81,16 @@ class ParamStore:
 class Conv:
     """3x3 / 1x1 convolution (bias-free) with forward, data-gradient and weight-gradient launches."""
 
-    def __init__(self, store, name, cin_real, cout_real, k, stride, gen):
+    def __init__(self, store, name, cin_real, cout_real, k, stride, gen, init="kaiming_a0"):
         self.store, self.name = store, name
         self.cin_real, self.cout_real, self.k, self.stride = cin_real, cout_real, k, stride
         self.cin, self.cout = _pad32(cin_real), _pad32(cout_real)
         self.taps = k * k
         fan_in = cin_real * k * k
-        bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)   # init.kaiming_uniform_(w), a=0
+        if init == "kaiming_a0":       # pytorchcv: init.kaiming_uniform_(w)  (a = 0)
+            bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)
+        else:                          # nn.Conv2d default: kaiming_uniform_(w, a=sqrt(5))
+            bound = 1.0 / math.sqrt(fan_in)
 
         def init(v):
             v.zero_()
@@ -203,8 +206,8 @@ class _Engine:
             self._bufs[k] = ops.padded(B, H, W, C, self.device)
         return self._bufs[k]
 
-    def conv(self, name, cin, cout, k, stride):
-        c = Conv(self.store, name, cin, cout, k, stride, self.gen)
+    def conv(self, name, cin, cout, k, stride, init="kaiming_a0"):
+        c = Conv(self.store, name, cin, cout, k, stride, self.gen, init)
         self.convs.append(c)
         return c
 
@@ -231,11 +234,53 @@ class _Engine:
         self.store.zero_grad()
 
     # ---- logical (reference-named) parameter / buffer views for state_dict compatibility
+    def extra_param_views(self, buf):
+        """name -> view for parameters that are not Conv/BatchNorm objects (stem, classifier)."""
+        return {}
+
     def named_params(self, which="flat"):
-        raise NotImplementedError
+        buf = {"flat": self.store.flat, "grad": self.store.grad, "bf16": self.store.bf16}[which]
+        out = dict(self.extra_param_views(buf))
+        for c in self.convs:
+            out[c.name] = c.logical(buf)
+        for b in self.bns:
+            out[b.name + ".weight"] = self.store._view(buf, b.name + ".weight")[:b.c_real]
+            out[b.name + ".bias"] = self.store._view(buf, b.name + ".bias")[:b.c_real]
+        return out
 
     def named_buffers(self):
-        raise NotImplementedError
+        out = {}
+        for b in self.bns:
+            out[b.name + ".running_mean"] = b.running_mean[:b.c_real]
+            out[b.name + ".running_var"] = b.running_var[:b.c_real]
+            out[b.name + ".num_batches_tracked"] = torch.tensor(b.num_batches_tracked, dtype=torch.long)
+        return out
+
+    def load_state_dict(self, sd):
+        """Copy a reference-named state dict (fp32 tensors, any device) into the engine."""
+        params, bufs = self.named_params("flat"), self.named_buffers()
+        missing = {m for m in (set(params) | set(bufs)) - set(sd) if not m.endswith("num_batches_tracked")}
+        if missing:
+            raise KeyError(f"state dict is missing {sorted(missing)[:5]} ...")
+        for name, view in list(params.items()) + list(bufs.items()):
+            if name in sd and not name.endswith("num_batches_tracked"):
+                view.copy_(sd[name].to(self.device))
+        for b in self.bns:
+            if b.name + ".num_batches_tracked" in sd:
+                b.num_batches_tracked = int(sd[b.name + ".num_batches_tracked"])
+        self.store.refresh_bf16()
+        self.refresh_derived_weights()
+
+    def state_dict(self):
+        out = {k: v.detach().clone().contiguous() for k, v in self.named_params("flat").items()}
+        out.update({k: v.detach().clone() for k, v in self.named_buffers().items()})
+        return out
+
+    def _tensor(self, key, shape):
+        k = (key,) + tuple(shape)
+        if k not in self._bufs:
+            self._bufs[k] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        return self._bufs[k]
 
 
 class WRNEngine(_Engine):
@@ -321,12 +366,6 @@ class WRNEngine(_Engine):
         ops.linear_fwd(self._pooled, self.store.p("output.weight"), self.store.p("output.bias"), z)
         return z
 
-    def _tensor(self, key, shape):
-        k = (key,) + tuple(shape)
-        if k not in self._bufs:
-            self._bufs[k] = torch.empty(shape, dtype=torch.float32, device=self.device)
-        return self._bufs[k]
-
     def grad_buckets(self):
         """(lo, hi) ranges of the flat gradient buffer in the order backward completes them:
         [stage3 .. classifier], [stage2], [stem .. stage1]."""
@@ -387,48 +426,174 @@ class WRNEngine(_Engine):
             comm.finish(st.grad)
 
     # ------------------------------------------------------------------ reference-named views
-    def named_params(self, which="flat"):
-        buf = {"flat": self.store.flat, "grad": self.store.grad}[which]
-        out = {}
-        out["features.init_block.weight"] = (
-            self.store._view(buf, "features.init_block.weight").permute(0, 3, 1, 2))
-        for c in self.convs:
-            out[c.name] = c.logical(buf)
-        for b in self.bns:
-            out[b.name + ".weight"] = self.store._view(buf, b.name + ".weight")[:b.c_real]
-            out[b.name + ".bias"] = self.store._view(buf, b.name + ".bias")[:b.c_real]
-        out["output.weight"] = self.store._view(buf, "output.weight")
-        out["output.bias"] = self.store._view(buf, "output.bias")
-        return out
+    def extra_param_views(self, buf):
+        return {
+            "features.init_block.weight": self.store._view(buf, "features.init_block.weight").permute(0, 3, 1, 2),
+            "output.weight": self.store._view(buf, "output.weight"),
+            "output.bias": self.store._view(buf, "output.bias"),
+        }
 
-    def named_buffers(self):
-        out = {}
-        for b in self.bns:
-            out[b.name + ".running_mean"] = b.running_mean[:b.c_real]
-            out[b.name + ".running_var"] = b.running_var[:b.c_real]
-            out[b.name + ".num_batches_tracked"] = torch.tensor(b.num_batches_tracked, dtype=torch.long)
-        return out
 
-    def load_state_dict(self, sd):
-        """Copy a pytorchcv-named state dict (fp32 tensors, any device) into the engine."""
-        params, bufs = self.named_params("flat"), self.named_buffers()
-        missing = (set(params) | set(bufs)) - set(sd)
-        missing = {m for m in missing if not m.endswith("num_batches_tracked")}
-        if missing:
-            raise KeyError(f"state dict is missing {sorted(missing)[:5]} ...")
-        for name, view in list(params.items()) + list(bufs.items()):
-            if name in sd and not name.endswith("num_batches_tracked"):
-                view.copy_(sd[name].to(self.device))
-        for b in self.bns:
-            if b.name + ".num_batches_tracked" in sd:
-                b.num_batches_tracked = int(sd[b.name + ".num_batches_tracked"])
-        self.store.refresh_bf16()
-        self.refresh_derived_weights()
+class ResNetEngine(_Engine):
+    """CIFAR-style ResNet of the reference (nbdt/models/resnet.py:42-74 BasicBlock, :115-149 ResNet,
+    :171-179 ResNet18): 3x3 stem, 4 stages of post-activation BasicBlocks, global average pool,
+    ``linear``.  State-dict names are the reference's (conv1, bn1, layerN.M.*, shortcut.0/1, linear)."""
 
-    def state_dict(self):
-        out = {k: v.detach().clone().contiguous() for k, v in self.named_params("flat").items()}
-        out.update({k: v.detach().clone() for k, v in self.named_buffers().items()})
-        return out
+    def __init__(self, num_classes=10, num_blocks=(2, 2, 2, 2), device="cuda", seed=0):
+        super().__init__(device, seed)
+        self.num_classes = num_classes
+        gen = self.gen
+        self.stem_c = 64
+        b0 = 1.0 / math.sqrt(27)
+        self.store.add("conv1.weight", (64, 3, 3, 3), lambda v: v.uniform_(-b0, b0, generator=gen))
+        self.bn0 = self.bn("bn1", 64)
+        self.blocks = []
+        cin = 64
+        for i, (cout, stride0, n) in enumerate(zip((64, 128, 256, 512), (1, 2, 2, 2), num_blocks)):
+            for j in range(n):
+                stride = stride0 if j == 0 else 1
+                pre = f"layer{i + 1}.{j}."
+                short = stride != 1 or cin != cout
+                blk = {
+                    "conv1": self.conv(pre + "conv1.weight", cin, cout, 3, stride, init="torch_default"),
+                    "bn1": self.bn(pre + "bn1", cout),
+                    "conv2": self.conv(pre + "conv2.weight", cout, cout, 3, 1, init="torch_default"),
+                    "bn2": self.bn(pre + "bn2", cout),
+                    "sconv": self.conv(pre + "shortcut.0.weight", cin, cout, 1, stride, init="torch_default") if short else None,
+                    "sbn": self.bn(pre + "shortcut.1", cout) if short else None,
+                    "cin": cin, "cout": cout, "stride": stride, "key": f"l{i + 1}b{j}",
+                }
+                self.blocks.append(blk)
+                cin = cout
+        self.feat_c = cin
+        kb = 1.0 / math.sqrt(cin)
+        self.store.add("linear.weight", (num_classes, cin), lambda v: v.uniform_(-kb, kb, generator=gen))
+        self.store.add("linear.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
+        self.finalize()
+        dev = self.device
+        # identity "BN" for the plain average-pool head (features are already post-ReLU)
+        self._id_mean = torch.zeros(cin, device=dev)
+        self._id_rstd = torch.ones(cin, device=dev)
+        self._id_gamma = torch.ones(cin, device=dev)
+        self._id_beta = torch.zeros(cin, device=dev)
+        self._id_dsum = torch.zeros(2 * cin, device=dev)
+
+    def extra_param_views(self, buf):
+        return {
+            "conv1.weight": self.store._view(buf, "conv1.weight").permute(0, 3, 1, 2),
+            "linear.weight": self.store._view(buf, "linear.weight"),
+            "linear.bias": self.store._view(buf, "linear.bias"),
+        }
+
+    def grad_buckets(self):
+        ent = self.store.entries
+        l3 = ent["layer3.0.conv1.weight"][0]
+        l2 = ent["layer2.0.conv1.weight"][0]
+        return [(l3, self.store.grad.numel()), (l2, l3), (0, l2)]
+
+    def forward(self, img, training=None):
+        training = self.training if training is None else training
+        if img.dtype != torch.float32 or not img.is_contiguous():
+            img = img.float().contiguous()
+        B, _, H, W = img.shape
+        self._img, self._B = img, B
+        t0 = self.buf("t0", B, H, W, 64)
+        x = self.buf("a0", B, H, W, 64)
+        ops.stem_conv(img, self.store.p("conv1.weight"), t0, 64)
+        self.bn0.stats(t0, training)
+        self.bn0.apply(t0, x, relu=True)
+        h, w = H, W
+        for blk in self.blocks:
+            k, s, cin, cout = blk["key"], blk["stride"], blk["cin"], blk["cout"]
+            ho, wo = h // s, w // s
+            t1 = self.buf(k + ".t1", B, ho, wo, cout)
+            a1 = self.buf(k + ".a1", B, ho, wo, cout)
+            t2 = self.buf(k + ".t2", B, ho, wo, cout)
+            out = self.buf(k + ".out", B, ho, wo, cout)
+            blk["conv1"].forward(x, t1)
+            blk["bn1"].stats(t1, training)
+            blk["bn1"].apply(t1, a1, relu=True)
+            blk["conv2"].forward(a1, t2)
+            blk["bn2"].stats(t2, training)
+            if blk["sconv"] is not None:
+                ts = self.buf(k + ".ts", B, ho, wo, cout)
+                sc = self.buf(f"sc{cout}", B, ho, wo, cout)
+                blk["sconv"].forward(x, ts)
+                blk["sbn"].stats(ts, training)
+                blk["sbn"].apply(ts, sc, relu=False)
+                res = sc
+            else:
+                res = x
+            blk["bn2"].apply(t2, out, relu=True, residual=res)
+            blk["x_in"] = x
+            x, h, w = out, ho, wo
+        self._x_last, self._hw = x, (h, w)
+        self._pooled = self._tensor("pooled", (B, self.feat_c))
+        ops.bn_relu_pool(x, self._id_mean, self._id_rstd, self._id_gamma, self._id_beta, self._pooled)
+        z = self._tensor("z", (B, self.num_classes))
+        ops.linear_fwd(self._pooled, self.store.p("linear.weight"), self.store.p("linear.bias"), z)
+        return z
+
+    def backward(self, gz, comm=None):
+        B = self._B
+        gz = gz.contiguous()
+        st = self.store
+        buckets = self.grad_buckets() if comm is not None else None
+        gpool = self._tensor("gpool", (B, self.feat_c))
+        ops.linear_bwd(self._pooled, st.p("linear.weight"), gz, gpool, st.g("linear.weight"), st.g("linear.bias"))
+        h, w = self._hw
+        g = self.buf(f"g_out{self.feat_c}", B, h, w, self.feat_c)
+        # plain avg-pool backward: identity BN with zero batch sums (the x>0 mask it applies is the
+        # same mask the following ReLU backward applies anyway)
+        from nbdt._C import check, lib, ptr
+        check(lib().nbdt_pool_bn_bwd_apply(ptr(gpool), ptr(self._x_last), ptr(self._id_mean), ptr(self._id_rstd),
+                                           ptr(self._id_gamma), ptr(self._id_beta), ptr(self._id_dsum), B, h, w,
+                                           self.feat_c, ptr(g), ops.stream_ptr(self.device)))
+        toggle = 0
+        for blk in reversed(self.blocks):
+            k, s, cin, cout = blk["key"], blk["stride"], blk["cin"], blk["cout"]
+            ho, wo = h, w
+            hi, wi = ho * s, wo * s
+            tag = ("@" + k) if self.debug_keep else ""
+            t1 = self.buf(k + ".t1", B, ho, wo, cout)
+            a1 = self.buf(k + ".a1", B, ho, wo, cout)
+            t2 = self.buf(k + ".t2", B, ho, wo, cout)
+            out = self.buf(k + ".out", B, ho, wo, cout)
+            gt2 = self.buf(f"gt2_{cout}{tag}", B, ho, wo, cout)
+            ga1 = self.buf(f"ga1_{cout}{tag}", B, ho, wo, cout)
+            gt1 = self.buf(f"gt1_{cout}{tag}", B, ho, wo, cout)
+            toggle ^= 1
+            g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
+            x_in = blk["x_in"]
+            if blk["sconv"] is not None:
+                gsc = self.buf(f"gsc_{cout}{tag}", B, ho, wo, cout)
+                gts = self.buf(f"gts_{cout}{tag}", B, ho, wo, cout)
+                blk["bn2"].backward(g, out, t2, gt2, relu=True, g_resid=gsc)
+            else:
+                # identity shortcut: the masked gradient IS part of the block-input gradient
+                blk["bn2"].backward(g, out, t2, gt2, relu=True, g_resid=g_in)
+            blk["conv2"].backward_weight(a1, gt2)
+            blk["conv2"].backward_data(gt2, ga1)
+            blk["bn1"].backward(ga1, a1, t1, gt1, relu=True)
+            blk["conv1"].backward_weight(x_in, gt1)
+            if blk["sconv"] is not None:
+                blk["conv1"].backward_data(gt1, g_in)
+                ts = self.buf(k + ".ts", B, ho, wo, cout)
+                blk["sbn"].backward(gsc, None, ts, gts, relu=False)
+                blk["sconv"].backward_weight(x_in, gts)
+                blk["sconv"].backward_data(gts, g_in, accumulate=True)
+            else:
+                blk["conv1"].backward_data(gt1, g_in, accumulate=True)
+            blk["dbg"] = {"g_out": g, "g_in": g_in}
+            g, h, w = g_in, hi, wi
+            if comm is not None and k in ("l3b0", "l2b0"):
+                comm.reduce_range(st.grad, *buckets[0 if k == "l3b0" else 1])
+        gt0 = self.buf("gt0", B, h, w, 64)
+        self.bn0.backward(g, self.buf("a0", B, h, w, 64), self.buf("t0", B, h, w, 64), gt0, relu=True)
+        ops.stem_wgrad(self._img, gt0, st.g("conv1.weight"), 64)
+        if comm is not None:
+            comm.reduce_range(st.grad, *buckets[2])
+            comm.finish(st.grad)
 
 
 def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None):

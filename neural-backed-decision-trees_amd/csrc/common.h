@@ -93,6 +93,9 @@ __device__ __forceinline__ int pad_offset(const PadGeom& g, int p) {
   return (int)b * g.img + (h + 1) * g.row + (w + 1) * g.C;
 }
 
+// wgrad_dma.hip: LDS-DMA + transpose-read weight-gradient kernel (default path of nbdt_conv_wgrad)
+int wgrad_dma(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
+
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   __syncthreads();
   for (int it = 0; it < nk; ++it) {
     const int cur = it & 1;
-    if (++kc == kchunks) { kc = 0; ++tap; }
+    // tap is the FAST loop index: a 32-channel slice of the block's input rows (+halo) is 64 B per
+    // pixel, so the 9 shifted re-reads of it stay inside the XCD's 4 MiB L2 (tap-outer order kept
+    // the whole 320-B pixel live across taps: 7 MB per XCD, measured 3-6x over-fetch from HBM/MALL)
+    if (++tap == d.ntaps) { tap = 0; ++kc; }
     const bool more = it + 1 < nk;
     if (more) load_tile(tap, kc);
     compute(cur);

@@ -25,6 +25,7 @@
 //
 // Roofline: MFMA-bound, flops = 2*M*cout*cin*ntaps.
 #include "common.h"
+#include <stdlib.h>
 
 using namespace nbdt;
 
@@ -248,7 +249,7 @@ extern "C" int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const vo
   NBDT_REQUIRE(d && x && gy && dw, "null argument");
   NBDT_REQUIRE(d->cin > 0 && d->cin % 32 == 0 && d->cout > 0 && d->cout % 32 == 0, "channels must be multiples of 32");
   NBDT_REQUIRE(d->ntaps >= 1 && d->ntaps <= 9 && d->w_ntaps >= 1, "bad tap table");
-  NBDT_REQUIRE(d->B > 0 && d->gh > 0 && d->gw > 0 && d->gw % 4 == 0, "pixel grid width must be a multiple of 4");
+  NBDT_REQUIRE(d->B > 0 && d->gh > 0 && d->gw > 0, "empty pixel grid");
   for (int t = 0; t < d->ntaps; ++t) {
     NBDT_REQUIRE(d->w_tap[t] >= 0 && d->w_tap[t] < d->w_ntaps, "bad w_tap");
     NBDT_REQUIRE(d->tap_off[t] % 8 == 0, "tap offsets must be 16-byte aligned");
@@ -256,6 +257,13 @@ extern "C" int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const vo
   NBDT_REQUIRE(d->x_bs % 8 == 0 && d->x_hs % 8 == 0 && d->x_ws % 8 == 0 && d->x_base % 8 == 0 &&
                d->g_bs % 8 == 0 && d->g_hs % 8 == 0 && d->g_ws % 8 == 0 && d->g_base % 8 == 0,
                "pixel offsets must be 16-byte aligned");
+  const int64_t M_all = (int64_t)d->B * d->gh * d->gw;
+  NBDT_REQUIRE(M_all < (1ll << 31), "pixel grid too large");
+  // default: v3 (LDS-DMA + transpose reads, wgrad_dma.hip).  NBDT_WGRAD_V2=1 selects the
+  // register-staged v2 kernel below (kept for A/B measurements; needs gw % 4 == 0).
+  static const bool use_v2 = getenv("NBDT_WGRAD_V2") != nullptr;
+  if (!use_v2) return nbdt::wgrad_dma(d, x, gy, dw, (hipStream_t)stream);
+  NBDT_REQUIRE(d->gw % 4 == 0, "v2 wgrad: pixel grid width must be a multiple of 4");
   WgradParams p;
   p.d = *d;
   p.x = (const bf16_t*)x;

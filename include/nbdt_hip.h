@@ -113,6 +113,12 @@ typedef struct nbdt_conv_desc {
 int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                     const void* residual, void* stream);
 
+/* same launch, and the epilogue also accumulates the per-channel sum / sum of squares of the (bf16)
+ * output into bn_scratch[NBDT_BN_SLOTS][2][cout] -- the statistics the following BatchNorm needs, so
+ * nbdt_bn_finalize can replace nbdt_bn_stats (no second pass over the tensor). */
+int nbdt_conv_igemm_stats(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                          const void* residual, float* bn_scratch, void* stream);
+
 /* weight gradient (replaces cuDNN wgrad): dw[cout][w_ntaps][cin] fp32 += sum over the pixel grid
  * of gy[pix_g(m)][co] * x[pix_x(m) + tap_off[t]][ci]; split over pixels with fp32 atomics, so dw
  * must be zeroed (or hold the running .grad) before the call. */
@@ -138,27 +144,34 @@ int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, vo
  * Replaces nn.BatchNorm2d (train mode, eps 1e-5, momentum 0.1) + F.relu + residual adds
  * (nbdt/models/resnet.py:69-74; pytorchcv PreResUnit) and their autograd.  Tensors are padded
  * NHWC bf16 [B][H+2][W+2][C], C % 8 == 0; only interiors are read/written.  `scratch` is
- * NBDT_BN_SLOTS*2*C fp32 of caller-owned workspace (contents overwritten). */
+ * NBDT_BN_SLOTS*2*C fp32 of caller-owned workspace that must be ZERO on entry; every call leaves it
+ * zero again (the fold kernel clears what it read), so one zero-initialised buffer serves all layers. */
 #define NBDT_BN_SLOTS 32
 /* batch statistics: save_mean/save_rstd [C]; updates running_mean/var (unbiased var) if non-NULL */
 int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps,
                   float momentum, float* running_mean, float* running_var, float* scratch,
                   float* save_mean, float* save_rstd, void* stream);
+/* second half of nbdt_bn_stats alone: fold sums already accumulated in `scratch` (by
+ * nbdt_conv_igemm_stats) into save_mean/save_rstd + running statistics; re-zeroes scratch */
+int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
+                     float* running_mean, float* running_var, float* scratch, float* save_mean,
+                     float* save_rstd, void* stream);
 /* y = relu?( (x-mean)*rstd*gamma + beta [+ residual] ) */
 int nbdt_bn_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
                   const float* beta, const void* residual, int32_t relu, int32_t B, int32_t H,
                   int32_t W, int32_t C, void* y, void* stream);
-/* backward, pass 1: with gy' = gy * (y > 0) when relu (y = the forward output), writes
- * dsum[0][c] = sum gy', dsum[1][c] = sum gy' * xhat and accumulates dbeta += dsum[0],
- * dgamma += dsum[1] (either may be NULL). */
+/* backward, pass 1: with gy' = gy * mask when relu, writes dsum[0][c] = sum gy',
+ * dsum[1][c] = sum gy' * xhat and accumulates dbeta += dsum[0], dgamma += dsum[1] (either may be
+ * NULL).  mask = (y > 0) from the stored forward output y; with y == NULL (no residual in the
+ * forward) it is recomputed from x, gamma, beta with bn_apply's own expression -- one tensor read less. */
 int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float* save_mean,
-                       const float* save_rstd, int32_t relu, int32_t B, int32_t H, int32_t W,
-                       int32_t C, float* scratch, float* dsum, float* dgamma, float* dbeta,
-                       void* stream);
+                       const float* save_rstd, const float* gamma, const float* beta, int32_t relu,
+                       int32_t B, int32_t H, int32_t W, int32_t C, float* scratch, float* dsum,
+                       float* dgamma, float* dbeta, void* stream);
 /* backward, pass 2: gx = gamma*rstd*(gy' - (dsum0 + xhat*dsum1)/N) [+ gx_add];
  * g_resid (nullable) receives gy' (the gradient of the residual input). */
 int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float* save_mean,
-                      const float* save_rstd, const float* gamma, const float* dsum,
+                      const float* save_rstd, const float* gamma, const float* beta, const float* dsum,
                       const void* gx_add, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
                       void* gx, void* g_resid, void* stream);
 /* head: pooled[b][c] = mean over (h,w) of relu(bn(x))  (post_activ + final_pool / avg_pool2d,

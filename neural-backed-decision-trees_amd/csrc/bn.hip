@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kMaxThreads) void bn_stats_kernel(const bf16_t* __r
 }
 
 // 1 block: fold slots; mode 0 = forward statistics, mode 1 = backward sums
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ scratch, int C, float n,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ scratch, int C, float n,
                                                           float eps, float momentum,
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var,
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     for (int k = 0; k < kSlots; ++k) {
       s += scratch[((size_t)k * 2 + 0) * C + c];
       sq += scratch[((size_t)k * 2 + 1) * C + c];
+      scratch[((size_t)k * 2 + 0) * C + c] = 0.f;   // leave the slots zeroed for the next user
+      scratch[((size_t)k * 2 + 1) * C + c] = 0.f;
     }
     const float mean = s / n;
     float var = sq / n - mean * mean;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ scratch, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ scratch, int C,
                                                               float* __restrict__ dsum,
                                                               float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
@@ -112,6 +114,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     for (int k = 0; k < kSlots; ++k) {
       s0 += scratch[((size_t)k * 2 + 0) * C + c];
       s1 += scratch[((size_t)k * 2 + 1) * C + c];
+      scratch[((size_t)k * 2 + 0) * C + c] = 0.f;
+      scratch[((size_t)k * 2 + 1) * C + c] = 0.f;
     }
     dsum[c] = s0;
     dsum[C + c] = s1;
@@ -153,7 +157,9 @@ __global__ __launch_bounds__(kMaxThreads) void bn_apply_kernel(const bf16_t* __r
   }
 }
 
-// backward pass 1.  POOL: gy comes from gpooled[b][c]/(H*W) and the relu mask is recomputed from x.
+// backward pass 1.  POOL: gy comes from gpooled[b][c]/(H*W).  When POOL (or y == nullptr with RELU) the
+// relu mask is recomputed as (x*sc + sh > 0) with the exact expression bn_apply_kernel evaluates, so the
+// forward output need not be re-read (saves one of three tensor reads per pass).
 template <bool RELU, bool POOL>
 __global__ __launch_bounds__(kMaxThreads) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gy,
                                                                     const float* __restrict__ gpooled,
@@ -166,13 +172,14 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_reduce_kernel(const bf16_t
                                                                     int c8, int PY, float* __restrict__ scratch) {
   extern __shared__ float lds[];
   const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
-  float mu[8], rs[8], ga[8], be[8];
+  const bool maskx = POOL || (RELU && y == nullptr);
+  float mu[8], rs[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = cx * 8 + i;
     mu[i] = mean[c];
     rs[i] = rstd[c];
-    if (POOL) { ga[i] = gamma[c]; be[i] = beta[c]; }
+    if (maskx) { sc[i] = gamma[c] * rs[i]; sh[i] = beta[c] - mu[i] * sc[i]; }
   }
   const float inv_hw = 1.f / (float)(g.H * g.W);
   const int hw = g.H * g.W;
@@ -189,13 +196,13 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_reduce_kernel(const bf16_t
       for (int i = 0; i < 8; ++i) fg[i] = gpooled[(size_t)b * g.C + cx * 8 + i] * inv_hw;
     } else {
       unpack8(*(const u32x4_t*)(gy + o), fg);
-      if (RELU) unpack8(*(const u32x4_t*)(y + o), fy);
+      if (RELU && !maskx) unpack8(*(const u32x4_t*)(y + o), fy);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float xh = (fx[i] - mu[i]) * rs[i];
       float gg = fg[i];
-      if (POOL) gg = (xh * ga[i] + be[i]) > 0.f ? gg : 0.f;
+      if (maskx) gg = (fx[i] * sc[i] + sh[i]) > 0.f ? gg : 0.f;
       else if (RELU) gg = fy[i] > 0.f ? gg : 0.f;
       acc[0][i] += gg;
       acc[1][i] += gg * xh;
@@ -213,15 +220,15 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
     bf16_t* __restrict__ g_resid) {
   const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
   const float inv_n = 1.f / (float)g.npix;
-  float mu[8], rs[8], ga[8], be[8], k0[8], k1[8], sc[8];
+  const bool maskx = POOL || (RELU && y == nullptr);
+  float mu[8], rs[8], sh[8], k0[8], k1[8], sc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = cx * 8 + i;
     mu[i] = mean[c];
     rs[i] = rstd[c];
-    ga[i] = gamma[c];
-    if (POOL) be[i] = beta[c];
-    sc[i] = ga[i] * rs[i];
+    sc[i] = gamma[c] * rs[i];
+    if (maskx) sh[i] = beta[c] - mu[i] * sc[i];
     k0[i] = dsum[c] * inv_n;
     k1[i] = dsum[g.C + c] * inv_n;
   }
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
       for (int i = 0; i < 8; ++i) fg[i] = gpooled[(size_t)b * g.C + cx * 8 + i] * inv_hw;
     } else {
       unpack8(*(const u32x4_t*)(gy + o), fg);
-      if (RELU) unpack8(*(const u32x4_t*)(y + o), fy);
+      if (RELU && !maskx) unpack8(*(const u32x4_t*)(y + o), fy);
     }
     if (HAS_ADD) unpack8(*(const u32x4_t*)(gx_add + o), fa);
     float out[8];
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
     for (int i = 0; i < 8; ++i) {
       const float xh = (fx[i] - mu[i]) * rs[i];
       float gg = fg[i];
-      if (POOL) gg = (xh * ga[i] + be[i]) > 0.f ? gg : 0.f;
+      if (maskx) gg = (fx[i] * sc[i] + sh[i]) > 0.f ? gg : 0.f;
       else if (RELU) gg = fy[i] > 0.f ? gg : 0.f;
       fg[i] = gg;
       float v = sc[i] * (gg - k0[i] - xh * k1[i]);
@@ -310,13 +317,25 @@ extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int
   hipStream_t st = (hipStream_t)stream;
   const PadGeom g = make_geom(B, H, W, C);
   const Layout l = layout_for(C);
-  NBDT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * kSlots * 2 * C, st));
   const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st, (const bf16_t*)x, g,
                      l.c8, l.py, scratch);
   NBDT_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, (float)g.npix, eps, momentum,
                      running_mean, running_var, save_mean, save_rstd);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
+                                float* running_mean, float* running_var, float* scratch, float* save_mean,
+                                float* save_rstd, void* stream) {
+  NBDT_REQUIRE(scratch && save_mean && save_rstd, "null argument");
+  NBDT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must be both set or both NULL");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, C,
+                     (float)((long long)B * H * W), eps, momentum, running_mean, running_var, save_mean, save_rstd);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -342,25 +361,25 @@ extern "C" int nbdt_bn_apply(const void* x, const float* save_mean, const float*
 }
 
 extern "C" int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float* save_mean,
-                                  const float* save_rstd, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
-                                  float* scratch, float* dsum, float* dgamma, float* dbeta, void* stream) {
+                                  const float* save_rstd, const float* gamma, const float* beta, int32_t relu,
+                                  int32_t B, int32_t H, int32_t W, int32_t C, float* scratch, float* dsum,
+                                  float* dgamma, float* dbeta, void* stream) {
   NBDT_REQUIRE(gy && x && save_mean && save_rstd && scratch && dsum, "null argument");
-  NBDT_REQUIRE(!relu || y, "relu backward needs the forward output y");
+  NBDT_REQUIRE(!relu || y || (gamma && beta), "relu backward needs y, or gamma+beta to recompute the mask");
   int rc = check_shape(B, H, W, C);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const PadGeom g = make_geom(B, H, W, C);
   const Layout l = layout_for(C);
-  NBDT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * kSlots * 2 * C, st));
   const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
   const dim3 grid(grid_for(g, l, 16)), blk(l.threads);
   if (relu)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), grid, blk, shmem, st, (const bf16_t*)gy, nullptr,
-                       (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, nullptr, nullptr, g, l.c8, l.py,
+                       (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
                        scratch);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), grid, blk, shmem, st, (const bf16_t*)gy, nullptr,
-                       (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, nullptr, nullptr, g, l.c8, l.py,
+                       (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
                        scratch);
   NBDT_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
@@ -369,11 +388,11 @@ extern "C" int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, 
 }
 
 extern "C" int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float* save_mean,
-                                 const float* save_rstd, const float* gamma, const float* dsum, const void* gx_add,
-                                 int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C, void* gx, void* g_resid,
-                                 void* stream) {
+                                 const float* save_rstd, const float* gamma, const float* beta, const float* dsum,
+                                 const void* gx_add, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
+                                 void* gx, void* g_resid, void* stream) {
   NBDT_REQUIRE(gy && x && save_mean && save_rstd && gamma && dsum && gx, "null argument");
-  NBDT_REQUIRE(!relu || y, "relu backward needs the forward output y");
+  NBDT_REQUIRE(!relu || y || beta, "relu backward needs y, or beta to recompute the mask");
   int rc = check_shape(B, H, W, C);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -382,7 +401,7 @@ extern "C" int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, c
   const dim3 grid(grid_for(g, l, 8)), blk(l.threads);
 #define NBDT_BA(R, A, G)                                                                                          \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<R, false, A, G>), grid, blk, 0, st, (const bf16_t*)gy, nullptr,          \
-                     (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, nullptr, dsum,               \
+                     (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum,                  \
                      (const bf16_t*)gx_add, g, l.c8, l.py, (bf16_t*)gx, (bf16_t*)g_resid)
   const bool a = gx_add != nullptr, r = g_resid != nullptr;
   if (relu) {
@@ -421,7 +440,6 @@ extern "C" int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, cons
   hipStream_t st = (hipStream_t)stream;
   const PadGeom g = make_geom(B, H, W, C);
   const Layout l = layout_for(C);
-  NBDT_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float) * kSlots * 2 * C, st));
   const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st,
                      nullptr, gpooled, nullptr, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,

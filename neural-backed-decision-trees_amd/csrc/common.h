@@ -96,6 +96,10 @@ __device__ __forceinline__ int pad_offset(const PadGeom& g, int p) {
 // wgrad_dma.hip: LDS-DMA + transpose-read weight-gradient kernel (default path of nbdt_conv_wgrad)
 int wgrad_dma(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
 
+// conv_dma.hip: LDS-DMA pipelined implicit GEMM (default path of nbdt_conv_igemm)
+int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
+                   float* stats, int M, hipStream_t st);
+
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {

@@ -27,6 +27,7 @@
 //
 // Roofline: MFMA-bound.  flops = 2*M*cout*ntaps*cin per launch.
 #include "common.h"
+#include <stdlib.h>
 
 using namespace nbdt;
 
@@ -225,8 +226,8 @@ static int launch(ConvParams& p, hipStream_t st) {
   return NBDT_OK;
 }
 
-extern "C" int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
-                               const void* residual, void* stream) {
+static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* residual,
+                           float* bn_scratch, void* stream) {
   NBDT_REQUIRE(d && in && w && out, "null argument");
   NBDT_REQUIRE(d->cin > 0 && d->cin % 32 == 0, "cin must be a multiple of 32");
   NBDT_REQUIRE(d->cout > 0 && d->cout % 32 == 0, "cout must be a multiple of 32");
@@ -249,11 +250,28 @@ extern "C" int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const vo
   NBDT_REQUIRE(M64 < (1ll << 31), "pixel grid too large");
   p.M = (int)M64;
   hipStream_t st = (hipStream_t)stream;
+  // default: v2 (LDS-DMA 3-stage pipeline, conv_dma.hip); NBDT_IGEMM_V1=1 keeps the register-staged
+  // kernel below for A/B measurements
+  static const bool use_v1 = getenv("NBDT_IGEMM_V1") != nullptr;
+  if (!use_v1) return nbdt::conv_igemm_dma(d, in, w, out, p.res, bn_scratch, p.M, st);
+  NBDT_REQUIRE(bn_scratch == nullptr, "fused BN statistics need the LDS-DMA kernel (unset NBDT_IGEMM_V1)");
   const int nt32 = d->cout / 32;
   if (nt32 % 5 == 0) return launch<5>(p, st);
   if (nt32 % 4 == 0) return launch<4>(p, st);
   if (nt32 % 2 == 0) return launch<2>(p, st);
   return launch<1>(p, st);
+}
+
+extern "C" int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                               const void* residual, void* stream) {
+  return conv_igemm_impl(d, in, w, out, residual, nullptr, stream);
+}
+
+extern "C" int nbdt_conv_igemm_stats(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                                     const void* residual, float* bn_scratch, void* stream) {
+  NBDT_REQUIRE(bn_scratch != nullptr, "null statistics workspace");
+  NBDT_REQUIRE(d && !d->accumulate, "fused statistics are for plain outputs");
+  return conv_igemm_impl(d, in, w, out, residual, bn_scratch, stream);
 }
 
 // ------------------------------------------------------------------------------------------

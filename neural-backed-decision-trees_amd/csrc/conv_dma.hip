@@ -1,0 +1,364 @@
+// Implicit-GEMM convolution v2: LDS-DMA staging with a 3-stage ring (gfx950 only).
+//
+// Same contract, tiling, MFMA mapping, LDS swizzle and epilogue as conv_igemm_kernel (conv.hip);
+// what changes is how tiles reach LDS:
+//
+//   v1: global_load_dwordx4 -> 28 staging VGPRs -> ds_write_b128, 2 LDS buffers, 1-deep prefetch,
+//       hipcc-placed waits.  rocprofv3: 33% SQ_WAIT_ANY + 41% SQ_WAIT_INST_ANY, 33% of MFMA peak.
+//   v2: global_load_lds_dwordx4 (no staging registers, no ds_write), 3 LDS stages, the DMA for K tile
+//       t+2 is issued right after the barrier that frees its slot, counted s_waitcnt vmcnt(N) + one raw
+//       s_barrier per K tile (the protocol proven in wgrad_dma.hip).
+//
+// global_load_lds writes LDS at (wave-uniform base + lane*16), so the [row][4 x 16 B] tile image is
+// linear; the bank-conflict swizzle moves to the SOURCE side: LDS position (row, c) receives data
+// chunk c ^ ((row>>2)&3), and fragment reads look data chunk c up at position c ^ ((row>>2)&3)
+// (same involution on both sides, cdna guide rule 21).
+// One wave-instruction = 16 rows x 64 B.  Each lane's pixel/weight-row offsets are fixed for the whole
+// block, so a DMA costs one 64-bit add.  The per-tap input offset lives in lane `tap` of a VGPR and is
+// fetched with v_readlane (no scalar memory load inside the pipeline).
+#include "common.h"
+#include <stdlib.h>
+
+using namespace nbdt;
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+using nbdt::u32x4_t;
+
+namespace nbdt {
+struct ConvDmaParams {
+  nbdt_conv_desc d;
+  const bf16_t* in;
+  const bf16_t* w;
+  bf16_t* out;
+  const bf16_t* res;
+  float* stats;        // nullable: [NBDT_BN_SLOTS][2][cout] per-channel sum / sum of squares of the output
+  int M, n_blocks, m_blocks, per_xcd;
+};
+}  // namespace nbdt
+
+constexpr int BM = 256;
+constexpr int BK = 32;
+constexpr int NSTAGE = 3;
+
+__device__ __forceinline__ int lds_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ int pix_offset(int m, int gh, int gw, int bs, int hs, int ws, int base) {
+  const int j = m % gw;
+  const int t = m / gw;
+  const int i = t % gh;
+  const int b = t / gh;
+  return b * bs + i * hs + j * ws + base;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// fewest DMAs any wave issues per stage: A = 16 instructions (4 per wave), W = BN/16 instructions
+// handed out as {(w+2)%4, +4, ..}
+constexpr int min_w_dma(int w_instr) {
+  int best = 1 << 30;
+  for (int w = 0; w < 4; ++w) {
+    int n = 0;
+    for (int id = (w + 2) & 3; id < w_instr; id += 4) ++n;
+    best = n < best ? n : best;
+  }
+  return best;
+}
+
+template <int NT, bool HAS_RES, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaParams p) {
+  constexpr int BN = 32 * NT;
+  constexpr int A_BYTES = BM * BK * 2;  // 16 KiB
+  constexpr int W_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = A_BYTES / 1024, W_INSTR = W_BYTES / 1024;
+  constexpr int IPW_W = (W_INSTR + 3) / 4;
+  constexpr int MINPW = A_INSTR / 4 + min_w_dma(W_INSTR);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int bid = blockIdx.x;
+  const int item = (bid & 7) * p.per_xcd + (bid >> 3);
+  if (item >= p.m_blocks * p.n_blocks) return;
+  const int m_blk = item / p.n_blocks;
+  const int n_blk = item - m_blk * p.n_blocks;
+  const int m0 = m_blk * BM;
+  const int n0 = n_blk * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const nbdt_conv_desc& d = p.d;
+
+#define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
+  const int cin = NBDT_PIN(d.cin), ntaps = NBDT_PIN(d.ntaps);
+  const int kchunks = cin >> 5;
+  const int nk = ntaps * kchunks;
+  const int w_row_len = d.w_ntaps * cin;
+  const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)p.w;
+  const bf16_t* in_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(in_u >> 32)) << 32) |
+                                          (unsigned)NBDT_PIN((unsigned)in_u));
+  const bf16_t* w_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(w_u >> 32)) << 32) |
+                                         (unsigned)NBDT_PIN((unsigned)w_u));
+#undef NBDT_PIN
+  // lane t (< ntaps) keeps tap t's input offset and weight k-offset; fetched with v_readlane
+  const int tap_in_v = lane < ntaps ? d.tap_off[lane < 9 ? lane : 0] : 0;
+  const int tap_w_v = lane < ntaps ? d.w_tap[lane < 9 ? lane : 0] * cin : 0;
+
+  // ---- DMA slot tables (fixed per block): position (row, cpos) receives data chunk cpos ^ swz(row)
+  const int cpos = lane & 3;
+  int a_src[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = (wave + 4 * k) * 16 + (lane >> 2);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    a_src[k] = pix_offset(m, d.gh, d.gw, d.in_bs, d.in_hs, d.in_ws, d.in_base) + ((cpos ^ ((row >> 2) & 3)) << 3);
+  }
+  int w_src[IPW_W];
+#pragma unroll
+  for (int k = 0; k < IPW_W; ++k) {
+    const int id = ((wave + 2) & 3) + 4 * k;
+    int row = id * 16 + (lane >> 2);
+    row = row < BN ? row : BN - 1;
+    w_src[k] = (n0 + row) * w_row_len + ((cpos ^ ((row >> 2) & 3)) << 3);
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  auto issue = [&](int slot, int tap, int kc) {
+    const int a_k = __builtin_amdgcn_readlane(tap_in_v, tap) + kc * BK;
+    const int w_k = __builtin_amdgcn_readlane(tap_w_v, tap) + kc * BK;
+    const unsigned dst0 = lds_base + slot * STAGE;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      glds16(in_base + (a_src[k] + a_k), __builtin_amdgcn_readfirstlane(dst0 + (wave + 4 * k) * 1024));
+#pragma unroll
+    for (int k = 0; k < IPW_W; ++k) {
+      const int id = ((wave + 2) & 3) + 4 * k;
+      if (id < W_INSTR)  // wave-uniform
+        glds16(w_base + (w_src[k] + w_k), __builtin_amdgcn_readfirstlane(dst0 + A_BYTES + id * 1024));
+    }
+  };
+
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_half = lane >> 5;
+
+  auto compute = [&](int slot) {
+    const unsigned char* As = smem + slot * STAGE;
+    const unsigned char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + frag_half;
+      bf16x8 pf[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        pf[tm] = *(const bf16x8*)(As + lds_off(wave * 64 + tm * 32 + frag_row, c));
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const bf16x8 wf = *(const bf16x8*)(Ws + lds_off(tn * 32 + frag_row, c));
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pf[tm], acc[tn][tm], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- pipeline over K tiles, tap fastest (see conv.hip for why)
+  int tap = 0, kc = 0;
+  auto advance = [&]() {
+    if (++tap == ntaps) { tap = 0; ++kc; }
+  };
+  issue(0, tap, kc);
+  advance();
+  if (nk > 1) { issue(1, tap, kc); advance(); }
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nk) {
+      int s2 = slot + 2;
+      s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
+      issue(s2, tap, kc);
+      advance();
+    }
+    compute(slot);
+    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+  }
+
+  // ---- epilogue through LDS.  The accumulator layout (lane = pixel, regs = 4 consecutive couts) would
+  // give 8-byte stores / residual loads scattered over 32 pixel rows per instruction (the v1 residual
+  // epilogue cost 84 us per launch).  Instead each wave transposes its 32-pixel x BN tile through a
+  // private LDS region: rows of PITCH = 2*BN + 16 bytes (16-B aligned, 2-way at worst for the 8-byte
+  // lane writes), then walks it with a FIXED 8-channel chunk per lane: 16-byte coalesced residual
+  // loads / output stores (20 lanes = one 320-B pixel row), and -- because the chunk is fixed -- the
+  // per-channel sum and sum of squares of the bf16 output fall out of the same pass in registers.  They
+  // feed the next BatchNorm (bn_finalize only), replacing a full re-read of the tensor (bn_stats_kernel).
+  constexpr int PITCH = 2 * BN + 16;
+  constexpr int REGION = 32 * PITCH;
+  constexpr int NCH = BN / 8;            // 8-channel chunks per row
+  constexpr int RL = 64 / NCH;           // row lanes: lanes [0, RL*NCH) are active in the row walk
+  constexpr int ROW_ITERS = (32 + RL - 1) / RL;
+  static_assert(4 * REGION + 4 * 64 * 4 + 2 * BN * 4 <= NSTAGE * STAGE, "epilogue does not fit in the ring");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every wave is done with the K ring
+  asm volatile("" ::: "memory");
+  unsigned char* region = smem + wave * REGION;
+  int* row_off = (int*)(smem + 4 * REGION) + wave * 64;      // element offset of each of the wave's 64 pixels
+  float* blk_stats = (float*)(smem + 4 * REGION + 4 * 64 * 4);  // [2][BN]
+  {
+    const int m = m0 + wave * 64 + lane;
+    row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
+    if (STATS) {
+      for (int i = tid; i < 2 * BN; i += 256) blk_stats[i] = 0.f;
+      __syncthreads();   // block-uniform: zeroed before any wave's atomics
+    }
+  }
+  const int ch = lane % NCH, rl = lane / NCH;
+  const bool walker = rl < RL;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    if (HAS_RES) {  // (1) residual rows -> LDS, coalesced
+      if (walker)
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          const int r = rl + it * RL;
+          if (r < 32) {
+            const int o = row_off[tm * 32 + r];
+            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+            if (o >= 0) v = *(const u32x4_t*)(p.res + o + ch * 8);
+            *(u32x4_t*)(region + r * PITCH + ch * 16) = v;
+          }
+        }
+    }
+    // (2) accumulators (+ residual, fp32, single rounding) -> bf16 -> LDS at [pixel][cout]
+    unsigned char* myrow = region + frag_row * PITCH + frag_half * 8;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v0 = acc[tn][tm][4 * q + 0], v1 = acc[tn][tm][4 * q + 1];
+        float v2 = acc[tn][tm][4 * q + 2], v3 = acc[tn][tm][4 * q + 3];
+        unsigned char* at = myrow + (tn * 32 + q * 8) * 2;
+        if (HAS_RES) {
+          const u32x2 r = *(const u32x2*)at;
+          v0 += __uint_as_float(r[0] << 16);
+          v1 += __uint_as_float(r[0] & 0xffff0000u);
+          v2 += __uint_as_float(r[1] << 16);
+          v3 += __uint_as_float(r[1] & 0xffff0000u);
+        }
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v0, v1);
+        pk[1] = pack_bf16x2(v2, v3);
+        *(u32x2*)at = pk;
+      }
+    // (3) walk the rows: coalesced 16-byte stores (+ statistics of the rounded values)
+    if (walker)
+#pragma unroll
+      for (int it = 0; it < ROW_ITERS; ++it) {
+        const int r = rl + it * RL;
+        if (r < 32) {
+          const int o = row_off[tm * 32 + r];
+          if (o >= 0) {
+            const u32x4_t v = *(const u32x4_t*)(region + r * PITCH + ch * 16);
+            *(u32x4_t*)(p.out + o + ch * 8) = v;
+            if (STATS) {
+              float f[8];
+              unpack8(v, f);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+            }
+          }
+        }
+      }
+  }
+  if (STATS) {
+    if (walker)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        atomicAdd(blk_stats + ch * 8 + i, s1[i]);
+        atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
+      }
+    __syncthreads();
+    float* slot = p.stats + (size_t)(blockIdx.x & (NBDT_BN_SLOTS - 1)) * 2 * d.cout;
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, c = i - which * BN;
+      atomicAdd(slot + (size_t)which * d.cout + n0 + c, blk_stats[i]);
+    }
+  }
+}
+
+namespace nbdt {
+
+template <int NT>
+static int launch_dma(ConvDmaParams& p, hipStream_t st) {
+  constexpr int BN = 32 * NT;
+  p.n_blocks = p.d.cout / BN;
+  p.m_blocks = (p.M + BM - 1) / BM;
+  const int items = p.m_blocks * p.n_blocks;
+  p.per_xcd = (items + 7) / 8;
+  const size_t shmem = (size_t)NSTAGE * ((BM * BK * 2) + (BN * BK * 2));
+  static bool attr_set = false;
+  if (!attr_set) {
+#define NBDT_ATTR(R, S)                                                                                         \
+  NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<NT, R, S>),           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+    NBDT_ATTR(true, true); NBDT_ATTR(true, false); NBDT_ATTR(false, true); NBDT_ATTR(false, false);
+#undef NBDT_ATTR
+    attr_set = true;
+  }
+  const dim3 grid(p.per_xcd * 8), blk(256);
+#define NBDT_GO(R, S) hipLaunchKernelGGL((conv_igemm_dma_kernel<NT, R, S>), grid, blk, shmem, st, p)
+  if (p.res != nullptr) { if (p.stats) NBDT_GO(true, true); else NBDT_GO(true, false); }
+  else { if (p.stats) NBDT_GO(false, true); else NBDT_GO(false, false); }
+#undef NBDT_GO
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+// called by nbdt_conv_igemm (conv.hip) after argument validation
+int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
+                   float* stats, int M, hipStream_t st) {
+  ConvDmaParams p;
+  p.d = *d;
+  p.in = (const bf16_t*)in;
+  p.w = (const bf16_t*)w;
+  p.out = (bf16_t*)out;
+  p.res = (const bf16_t*)res;
+  p.stats = stats;
+  p.M = M;
+  const int nt32 = d->cout / 32;
+  if (nt32 % 5 == 0) return launch_dma<5>(p, st);
+  if (nt32 % 4 == 0) return launch_dma<4>(p, st);
+  if (nt32 % 2 == 0) return launch_dma<2>(p, st);
+  return launch_dma<1>(p, st);
+}
+
+}  // namespace nbdt

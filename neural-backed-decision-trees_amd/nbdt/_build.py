@@ -23,6 +23,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 FLAGS = {
     "rules.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "conv.hip": ["-munsafe-fp-atomics"],
+    "conv_dma.hip": ["-munsafe-fp-atomics"],
     "wgrad.hip": ["-munsafe-fp-atomics"],
     "wgrad_dma.hip": ["-munsafe-fp-atomics"],
     "bn.hip": ["-munsafe-fp-atomics"],

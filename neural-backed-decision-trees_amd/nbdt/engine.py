@@ -123,9 +123,9 @@ class Conv:
                                   device=self.store.device)
         ops.weight_prep(self.store.p(self.name), self.cout, self.taps, self.cin, None, self.wd)
 
-    def forward(self, x, out, residual=None):
+    def forward(self, x, out, residual=None, bn_scratch=None):
         B, Hp, Wp, _ = x.shape
-        ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, residual)
+        ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, residual, bn_scratch)
 
     def backward_data(self, gout, gin, accumulate=False):
         B, Hp, Wp, _ = gin.shape
@@ -161,10 +161,11 @@ class BatchNorm:
     def beta(self):
         return self.store.p(self.name + ".bias")
 
-    def stats(self, x, training):
+    def stats(self, x, training, fused=False):
+        """fused=True: the producing conv's epilogue already accumulated the sums (finalize only)."""
         if training:
-            ops.bn_stats(x, self.owner.scratch(self.C), self.mean, self.rstd, self.running_mean,
-                         self.running_var)
+            fn = ops.bn_finalize if fused else ops.bn_stats
+            fn(x, self.owner.scratch(self.C), self.mean, self.rstd, self.running_mean, self.running_var)
             self.num_batches_tracked += 1
         else:  # eval: running statistics (two [C]-sized plumbing ops, not on the training path)
             self.mean.copy_(self.running_mean)
@@ -174,9 +175,10 @@ class BatchNorm:
         ops.bn_apply(x, self.mean, self.rstd, self.gamma, self.beta, y, relu=relu, residual=residual)
 
     def backward(self, gy, y, x, gx, relu=True, gx_add=None, g_resid=None):
+        """y=None: recompute the ReLU mask from x (valid when apply() had no residual)."""
         ops.bn_bwd(gy, y, x, self.mean, self.rstd, self.gamma, self.owner.scratch(self.C), self.dsum,
                    self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, relu=relu,
-                   gx_add=gx_add, g_resid=g_resid)
+                   gx_add=gx_add, g_resid=g_resid, beta=self.beta)
 
 
 class _Engine:
@@ -193,11 +195,13 @@ class _Engine:
         self.convs, self.bns = [], []
         self.training = True
         self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
+        self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
 
     def scratch(self, C):
         need = ops.BN_SLOTS * 2 * C
         if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(max(need, ops.BN_SLOTS * 2 * 2048), device=self.device)
+            # zero on entry is the C-ABI contract; the fold kernels re-zero what they read
+            self._scratch = torch.zeros(max(need, ops.BN_SLOTS * 2 * 2048), device=self.device)
         return self._scratch
 
     def buf(self, key, B, H, W, C):
@@ -335,6 +339,7 @@ class WRNEngine(_Engine):
         x = self.buf("x0", B, H, W, self.stem_cpad)
         ops.stem_conv(img, self.store.p("features.init_block.weight"), x, self.stem_c)
         h, w = H, W
+        x_has_stats = False   # the stem kernel does not produce BN sums
         for u in self.units:
             k, s = u["key"], u["stride"]
             cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
@@ -343,10 +348,11 @@ class WRNEngine(_Engine):
             t = self.buf(k + ".t", B, ho, wo, cout)
             a2 = self.buf(k + ".a2", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
-            u["bn1"].stats(x, training)
+            fuse = training and self.fuse_stats
+            u["bn1"].stats(x, training, fused=fuse and x_has_stats)
             u["bn1"].apply(x, a1, relu=True)
-            u["conv1"].forward(a1, t)
-            u["bn2"].stats(t, training)
+            u["conv1"].forward(a1, t, bn_scratch=self.scratch(cout) if fuse else None)
+            u["bn2"].stats(t, training, fused=fuse)
             u["bn2"].apply(t, a2, relu=True)
             if u["idconv"] is not None:
                 idn = self.buf(f"idn{cout}", B, ho, wo, cout)
@@ -354,11 +360,12 @@ class WRNEngine(_Engine):
                 res = idn
             else:
                 res = x
-            u["conv2"].forward(a2, out, residual=res)
+            u["conv2"].forward(a2, out, residual=res, bn_scratch=self.scratch(cout) if fuse else None)
+            x_has_stats = True
             u["x_in"], u["x_out"] = x, out
             x, h, w = out, ho, wo
         self._x_last, self._hw = x, (h, w)
-        self.post_bn.stats(x, training)
+        self.post_bn.stats(x, training, fused=training and self.fuse_stats)
         self._pooled = self._tensor("pooled", (B, self.feat_c))
         ops.bn_relu_pool(x, self.post_bn.mean, self.post_bn.rstd, self.post_bn.gamma, self.post_bn.beta,
                          self._pooled)
@@ -408,15 +415,15 @@ class WRNEngine(_Engine):
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             u["conv2"].backward_weight(a2, g)
             u["conv2"].backward_data(g, ga2)
-            u["bn2"].backward(ga2, a2, t, gt, relu=True)
+            u["bn2"].backward(ga2, None, t, gt, relu=True)       # mask recomputed from t: a2 not re-read
             u["conv1"].backward_weight(a1, gt)
             u["conv1"].backward_data(gt, ga1)
             if u["idconv"] is not None:
                 u["idconv"].backward_weight(a1, g)
                 u["idconv"].backward_data(g, ga1, accumulate=True)
-                u["bn1"].backward(ga1, a1, u["x_in"], g_in, relu=True)
+                u["bn1"].backward(ga1, None, u["x_in"], g_in, relu=True)
             else:
-                u["bn1"].backward(ga1, a1, u["x_in"], g_in, relu=True, gx_add=g)
+                u["bn1"].backward(ga1, None, u["x_in"], g_in, relu=True, gx_add=g)
             g, h, w = g_in, hi, wi
             if comm is not None and u["key"] in ("s3u1", "s2u1"):
                 comm.reduce_range(st.grad, *buckets[0 if u["key"] == "s3u1" else 1])
@@ -510,16 +517,18 @@ class ResNetEngine(_Engine):
             a1 = self.buf(k + ".a1", B, ho, wo, cout)
             t2 = self.buf(k + ".t2", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
-            blk["conv1"].forward(x, t1)
-            blk["bn1"].stats(t1, training)
+            fuse = training and self.fuse_stats
+            scr = self.scratch(cout) if fuse else None
+            blk["conv1"].forward(x, t1, bn_scratch=scr)
+            blk["bn1"].stats(t1, training, fused=fuse)
             blk["bn1"].apply(t1, a1, relu=True)
-            blk["conv2"].forward(a1, t2)
-            blk["bn2"].stats(t2, training)
+            blk["conv2"].forward(a1, t2, bn_scratch=scr)
+            blk["bn2"].stats(t2, training, fused=fuse)
             if blk["sconv"] is not None:
                 ts = self.buf(k + ".ts", B, ho, wo, cout)
                 sc = self.buf(f"sc{cout}", B, ho, wo, cout)
-                blk["sconv"].forward(x, ts)
-                blk["sbn"].stats(ts, training)
+                blk["sconv"].forward(x, ts, bn_scratch=scr)
+                blk["sbn"].stats(ts, training, fused=fuse)
                 blk["sbn"].apply(ts, sc, relu=False)
                 res = sc
             else:
@@ -574,7 +583,7 @@ class ResNetEngine(_Engine):
                 blk["bn2"].backward(g, out, t2, gt2, relu=True, g_resid=g_in)
             blk["conv2"].backward_weight(a1, gt2)
             blk["conv2"].backward_data(gt2, ga1)
-            blk["bn1"].backward(ga1, a1, t1, gt1, relu=True)
+            blk["bn1"].backward(ga1, None, t1, gt1, relu=True)
             blk["conv1"].backward_weight(x_in, gt1)
             if blk["sconv"] is not None:
                 blk["conv1"].backward_data(gt1, g_in)
@@ -589,7 +598,7 @@ class ResNetEngine(_Engine):
             if comm is not None and k in ("l3b0", "l2b0"):
                 comm.reduce_range(st.grad, *buckets[0 if k == "l3b0" else 1])
         gt0 = self.buf("gt0", B, h, w, 64)
-        self.bn0.backward(g, self.buf("a0", B, h, w, 64), self.buf("t0", B, h, w, 64), gt0, relu=True)
+        self.bn0.backward(g, None, self.buf("t0", B, h, w, 64), gt0, relu=True)
         ops.stem_wgrad(self._img, gt0, st.g("conv1.weight"), 64)
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])

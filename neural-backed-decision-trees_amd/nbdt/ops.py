@@ -183,14 +183,19 @@ def set_timer(t):
 # ------------------------------------------------------------------------------------------------
 # launches
 
-def conv_igemm(desc, inp, w_bf16, out, residual=None):
+def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
+    """bn_scratch: also accumulate the output's per-channel sum / sum-of-squares for the next BatchNorm."""
     ev = None
     if _timer is not None:
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
         ev = _timer.bracket("conv_igemm", flops, inp.device)
         ev[0].record()
-    check(lib().nbdt_conv_igemm(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
-                                stream_ptr(inp.device)))
+    if bn_scratch is None:
+        check(lib().nbdt_conv_igemm(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
+                                    stream_ptr(inp.device)))
+    else:
+        check(lib().nbdt_conv_igemm_stats(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
+                                          ptr(bn_scratch), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
 
@@ -223,6 +228,14 @@ def bn_stats(x, scratch, save_mean, save_rstd, running_mean=None, running_var=No
                               ptr(scratch), ptr(save_mean), ptr(save_rstd), stream_ptr(x.device)))
 
 
+def bn_finalize(x, scratch, save_mean, save_rstd, running_mean=None, running_var=None,
+                eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Fold sums that a conv epilogue already left in `scratch` (conv_igemm(..., bn_scratch=scratch))."""
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_finalize(B, H, W, C, eps, momentum, ptr(running_mean), ptr(running_var), ptr(scratch),
+                                 ptr(save_mean), ptr(save_rstd), stream_ptr(x.device)))
+
+
 def bn_apply(x, mean, rstd, gamma, beta, y, relu=True, residual=None):
     B, H, W, C = _dims(x)
     check(lib().nbdt_bn_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual),
@@ -230,14 +243,15 @@ def bn_apply(x, mean, rstd, gamma, beta, y, relu=True, residual=None):
 
 
 def bn_bwd(gy, y, x, mean, rstd, gamma, scratch, dsum, dgamma, dbeta, gx, relu=True, gx_add=None,
-           g_resid=None):
+           g_resid=None, beta=None):
+    """y=None (allowed when the forward had no residual): the ReLU mask is recomputed from x/gamma/beta."""
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
     r = 1 if relu else 0
-    check(lib().nbdt_bn_bwd_reduce(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), r, B, H, W, C,
-                                   ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
-    check(lib().nbdt_bn_bwd_apply(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dsum),
-                                  ptr(gx_add), r, B, H, W, C, ptr(gx), ptr(g_resid), st))
+    check(lib().nbdt_bn_bwd_reduce(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), r,
+                                   B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
+    check(lib().nbdt_bn_bwd_apply(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                  ptr(dsum), ptr(gx_add), r, B, H, W, C, ptr(gx), ptr(g_resid), st))
 
 
 def bn_relu_pool(x, mean, rstd, gamma, beta, pooled):

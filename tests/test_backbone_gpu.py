@@ -116,6 +116,31 @@ def test_conv_forward_dgrad_wgrad(B, H, W, cin, cout, k, stride):
     np.testing.assert_allclose(dw.cpu().numpy(), 2 * gw_ref.numpy(), rtol=2e-3, atol=4e-3 * gw_ref.abs().mean().item())
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,k,stride,res", [(4, 8, 8, 160, 160, 3, 1, True), (3, 16, 16, 32, 160, 3, 1, False),
+                                                         (5, 4, 4, 64, 128, 3, 1, True), (2, 8, 8, 160, 320, 3, 2, False),
+                                                         (3, 8, 8, 64, 64, 1, 1, False), (7, 4, 4, 96, 32, 1, 1, True)])
+def test_conv_epilogue_bn_statistics(B, H, W, cin, cout, k, stride, res):
+    """conv_igemm_stats: same output as the plain launch, and the accumulated sums == bn_stats of it."""
+    xf, xp = _rand_act(B, H, W, cin, seed=41)
+    _, w_int = _rand_weight(cout, cin, k, seed=42)
+    wb = w_int.to(torch.bfloat16).to(DEV)
+    Ho, Wo = H // stride, W // stride
+    rp = _rand_act(B, Ho, Wo, cout, seed=43)[1] if res else None
+    d = ops.conv_fwd_desc(B, H, W, cin, cout, k, stride)
+    out_a, out_b = ops.padded(B, Ho, Wo, cout, DEV), ops.padded(B, Ho, Wo, cout, DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * cout, device=DEV)
+    ops.conv_igemm(d, xp, wb, out_a, residual=rp)
+    ops.conv_igemm(d, xp, wb, out_b, residual=rp, bn_scratch=scratch)
+    assert torch.equal(out_a, out_b)
+    mean_f, rstd_f = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+    ops.bn_finalize(out_b, scratch, mean_f, rstd_f)
+    assert scratch.abs().max().item() == 0
+    mean_r, rstd_r = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+    ops.bn_stats(out_a, scratch, mean_r, rstd_r)
+    np.testing.assert_allclose(mean_f.cpu().numpy(), mean_r.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rstd_f.cpu().numpy(), rstd_r.cpu().numpy(), rtol=1e-4)
+
+
 def test_conv_identity_weights_are_transpose_detecting():
     # w[co][center][ci] = 1 if co == perm(ci): output channel co must equal input channel perm^-1(co)
     B, H, W, C = 2, 8, 8, 160
@@ -153,7 +178,7 @@ def test_batchnorm_forward_backward(B, H, W, C, relu, with_res):
     rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
     rf, rp = _rand_act(B, H, W, C, seed=13) if with_res else (None, None)
 
-    scratch = torch.empty(ops.BN_SLOTS * 2 * C, device=DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV)
     mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
     ops.bn_stats(xp, scratch, mean, rstd, rm, rv)
@@ -187,7 +212,16 @@ def test_batchnorm_forward_backward(B, H, W, C, relu, with_res):
     gres = ops.padded(B, H, W, C, DEV) if with_res else None
     af, ap = _rand_act(B, H, W, C, seed=15)
     ops.bn_bwd(gp, y, xp, mean, rstd, gamma.to(DEV), scratch, dsum, dgamma, dbeta, gx, relu=relu, gx_add=ap,
-               g_resid=gres)
+               g_resid=gres, beta=beta.to(DEV))
+    assert scratch.abs().max().item() == 0      # contract: the workspace is left zeroed
+    if relu and not with_res:
+        # mask recomputed from x instead of re-reading y: identical result
+        gx2 = ops.padded(B, H, W, C, DEV)
+        dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ops.bn_bwd(gp, None, xp, mean, rstd, gamma.to(DEV), scratch, dsum, dg2, db2, gx2, relu=True, gx_add=ap,
+                   beta=beta.to(DEV))
+        assert (gx2.float() - gx.float()).abs().max().item() <= 1e-2 * gx.float().abs().max().item()
+        np.testing.assert_allclose(dg2.cpu().numpy(), dgamma.cpu().numpy(), rtol=1e-3, atol=1e-3)
     # y values that round to exactly 0 in bf16 but are >0 in fp32 flip the mask for a few elements
     gx_ref = xt.grad.permute(0, 2, 3, 1) + af
     got = ops.interior(gx).float().cpu()
@@ -209,7 +243,7 @@ def test_head_pool_linear():
     g = torch.Generator().manual_seed(22)
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
     w, b = torch.randn(N, C, generator=g) / C ** 0.5, torch.randn(N, generator=g) * 0.1
-    scratch = torch.empty(ops.BN_SLOTS * 2 * C, device=DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV)
     mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     ops.bn_stats(xp, scratch, mean, rstd)
     pooled = torch.empty(B, C, device=DEV)

@@ -113,11 +113,12 @@ typedef struct nbdt_conv_desc {
 int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                     const void* residual, void* stream);
 
-/* same launch, and the epilogue also accumulates the per-channel sum / sum of squares of the (bf16)
- * output into bn_scratch[NBDT_BN_SLOTS][2][cout] -- the statistics the following BatchNorm needs, so
- * nbdt_bn_finalize can replace nbdt_bn_stats (no second pass over the tensor). */
+/* same launch, and the epilogue also writes the per-channel sum / sum of squares of the (bf16) output
+ * of every 256-pixel tile to bn_partials[ceil(M/256)][2][cout] (plain stores, fully overwritten) -- the
+ * statistics the following BatchNorm needs, so nbdt_bn_finalize can replace nbdt_bn_stats (no second
+ * pass over the tensor). */
 int nbdt_conv_igemm_stats(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
-                          const void* residual, float* bn_scratch, void* stream);
+                          const void* residual, float* bn_partials, void* stream);
 
 /* weight gradient (replaces cuDNN wgrad): dw[cout][w_ntaps][cin] fp32 += sum over the pixel grid
  * of gy[pix_g(m)][co] * x[pix_x(m) + tap_off[t]][ci]; split over pixels with fp32 atomics, so dw
@@ -151,10 +152,10 @@ int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, vo
 int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps,
                   float momentum, float* running_mean, float* running_var, float* scratch,
                   float* save_mean, float* save_rstd, void* stream);
-/* second half of nbdt_bn_stats alone: fold sums already accumulated in `scratch` (by
- * nbdt_conv_igemm_stats) into save_mean/save_rstd + running statistics; re-zeroes scratch */
+/* fold the partial sums nbdt_conv_igemm_stats wrote for a [B,H,W,C] output (ceil(B*H*W/256) rows) into
+ * save_mean/save_rstd + running statistics */
 int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
-                     float* running_mean, float* running_var, float* scratch, float* save_mean,
+                     float* running_mean, float* running_var, const float* bn_partials, float* save_mean,
                      float* save_rstd, void* stream);
 /* y = relu?( (x-mean)*rstd*gamma + beta [+ residual] ) */
 int nbdt_bn_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,

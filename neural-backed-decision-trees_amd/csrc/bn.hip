@@ -327,15 +327,52 @@ extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int
   return NBDT_OK;
 }
 
+// fold [rows][2][C] partial sums written by conv epilogues: block = 32 channels x 8 row-strides
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ part, int rows, int C,
+                                                               float n, float eps, float momentum,
+                                                               float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var,
+                                                               float* __restrict__ save_mean,
+                                                               float* __restrict__ save_rstd) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s = 0.f, sq = 0.f;
+  if (c < C)
+    for (int r = rs; r < rows; r += 8) {
+      s += part[((size_t)r * 2 + 0) * C + c];
+      sq += part[((size_t)r * 2 + 1) * C + c];
+    }
+  red[0][rs][cl] = s;
+  red[1][rs][cl] = sq;
+  __syncthreads();
+  if (rs == 0 && c < C) {
+    s = 0.f; sq = 0.f;
+    for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; sq += red[1][k][cl]; }
+    const float mean = s / n;
+    float var = sq / n - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    save_mean[c] = mean;
+    save_rstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+}
+
 extern "C" int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
-                                float* running_mean, float* running_var, float* scratch, float* save_mean,
+                                float* running_mean, float* running_var, const float* partials, float* save_mean,
                                 float* save_rstd, void* stream) {
-  NBDT_REQUIRE(scratch && save_mean && save_rstd, "null argument");
+  NBDT_REQUIRE(partials && save_mean && save_rstd, "null argument");
   NBDT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must be both set or both NULL");
   int rc = check_shape(B, H, W, C);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, C,
-                     (float)((long long)B * H * W), eps, momentum, running_mean, running_var, save_mean, save_rstd);
+  const long long npix = (long long)B * H * W;
+  const int rows = (int)((npix + 255) / 256);   // = the pixel tiles of nbdt_conv_igemm_stats
+  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, rows,
+                     C, (float)npix, eps, momentum, running_mean, running_var, save_mean, save_rstd);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

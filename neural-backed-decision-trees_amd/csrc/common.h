@@ -43,8 +43,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2 in ONE instruction (gfx950 v_cvt_pk_bf16_f32: round-to-nearest-even, NaN
+// preserved; bit-exactness vs torch's .to(bfloat16) is asserted by tests/test_backbone_gpu.py::test_sgd_*).
+// The integer formulation above costs ~10 VALU + a divergent NaN branch per element.
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 
 // exact n / d for 0 <= n < 2^31 with one mul-hi and one shift (host builds, device divides)

@@ -33,7 +33,7 @@ struct ConvDmaParams {
   const bf16_t* w;
   bf16_t* out;
   const bf16_t* res;
-  float* stats;        // nullable: [NBDT_BN_SLOTS][2][cout] per-channel sum / sum of squares of the output
+  float* stats;        // nullable: [m_blocks][2][cout] per-pixel-tile partial sum / sum of squares of the output
   int M, n_blocks, m_blocks, per_xcd;
 };
 }  // namespace nbdt
@@ -245,18 +245,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
 
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
-    if (HAS_RES) {  // (1) residual rows -> LDS, coalesced
-      if (walker)
+    if (HAS_RES) {  // (1) residual rows -> LDS, coalesced; all loads issued before the first LDS write
+      if (walker) {   // (unconditional loads: rows past M re-read row 0, their results are never stored)
+        u32x4_t rv[ROW_ITERS];
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          int r = rl + it * RL;
+          r = r < 32 ? r : 31;
+          int o = row_off[tm * 32 + r];
+          o = o >= 0 ? o : p.d.out_base + n0;
+          rv[it] = *(const u32x4_t*)(p.res + o + ch * 8);
+        }
 #pragma unroll
         for (int it = 0; it < ROW_ITERS; ++it) {
           const int r = rl + it * RL;
-          if (r < 32) {
-            const int o = row_off[tm * 32 + r];
-            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-            if (o >= 0) v = *(const u32x4_t*)(p.res + o + ch * 8);
-            *(u32x4_t*)(region + r * PITCH + ch * 16) = v;
-          }
+          if (r < 32) *(u32x4_t*)(region + r * PITCH + ch * 16) = rv[it];
         }
+      }
     }
     // (2) accumulators (+ residual, fp32, single rounding) -> bf16 -> LDS at [pixel][cout]
     unsigned char* myrow = region + frag_row * PITCH + frag_half * 8;
@@ -307,10 +312,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
         atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
       }
     __syncthreads();
-    float* slot = p.stats + (size_t)(blockIdx.x & (NBDT_BN_SLOTS - 1)) * 2 * d.cout;
+    // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost
+    // more than the separate statistics pass they replace); nbdt_bn_finalize folds the rows
+    float* part = p.stats + (size_t)m_blk * 2 * d.cout;
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, c = i - which * BN;
-      atomicAdd(slot + (size_t)which * d.cout + n0 + c, blk_stats[i]);
+      part[(size_t)which * d.cout + n0 + c] = blk_stats[i];
     }
   }
 }

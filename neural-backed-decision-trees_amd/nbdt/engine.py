@@ -162,10 +162,14 @@ class BatchNorm:
         return self.store.p(self.name + ".bias")
 
     def stats(self, x, training, fused=False):
-        """fused=True: the producing conv's epilogue already accumulated the sums (finalize only)."""
+        """fused=True: the producing conv's epilogue already wrote per-tile partial sums (fold only)."""
         if training:
-            fn = ops.bn_finalize if fused else ops.bn_stats
-            fn(x, self.owner.scratch(self.C), self.mean, self.rstd, self.running_mean, self.running_var)
+            if fused:
+                ops.bn_finalize(x, self.owner.partials(x), self.mean, self.rstd, self.running_mean,
+                                self.running_var)
+            else:
+                ops.bn_stats(x, self.owner.scratch(self.C), self.mean, self.rstd, self.running_mean,
+                             self.running_var)
             self.num_batches_tracked += 1
         else:  # eval: running statistics (two [C]-sized plumbing ops, not on the training path)
             self.mean.copy_(self.running_mean)
@@ -203,6 +207,14 @@ class _Engine:
             # zero on entry is the C-ABI contract; the fold kernels re-zero what they read
             self._scratch = torch.zeros(max(need, ops.BN_SLOTS * 2 * 2048), device=self.device)
         return self._scratch
+
+    def partials(self, out):
+        """Workspace for the conv-epilogue BN partial sums of a padded [B,H+2,W+2,C] output."""
+        B, Hp, Wp, C = out.shape
+        need = ((B * (Hp - 2) * (Wp - 2) + 255) // 256) * 2 * C
+        if getattr(self, "_partials", None) is None or self._partials.numel() < need:
+            self._partials = torch.empty(need, device=self.device)
+        return self._partials
 
     def buf(self, key, B, H, W, C):
         k = (key, B, H, W, C)
@@ -351,7 +363,7 @@ class WRNEngine(_Engine):
             fuse = training and self.fuse_stats
             u["bn1"].stats(x, training, fused=fuse and x_has_stats)
             u["bn1"].apply(x, a1, relu=True)
-            u["conv1"].forward(a1, t, bn_scratch=self.scratch(cout) if fuse else None)
+            u["conv1"].forward(a1, t, bn_scratch=self.partials(t) if fuse else None)
             u["bn2"].stats(t, training, fused=fuse)
             u["bn2"].apply(t, a2, relu=True)
             if u["idconv"] is not None:
@@ -360,7 +372,7 @@ class WRNEngine(_Engine):
                 res = idn
             else:
                 res = x
-            u["conv2"].forward(a2, out, residual=res, bn_scratch=self.scratch(cout) if fuse else None)
+            u["conv2"].forward(a2, out, residual=res, bn_scratch=self.partials(out) if fuse else None)
             x_has_stats = True
             u["x_in"], u["x_out"] = x, out
             x, h, w = out, ho, wo
@@ -518,7 +530,7 @@ class ResNetEngine(_Engine):
             t2 = self.buf(k + ".t2", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
             fuse = training and self.fuse_stats
-            scr = self.scratch(cout) if fuse else None
+            scr = self.partials(t1) if fuse else None
             blk["conv1"].forward(x, t1, bn_scratch=scr)
             blk["bn1"].stats(t1, training, fused=fuse)
             blk["bn1"].apply(t1, a1, relu=True)

@@ -34,6 +34,18 @@ for (H, cin, cout, k, st) in shapes:
     if 'fwd' in which:
         d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
         t = timeit(lambda: ops.conv_igemm(d, x, wb, out)); line += f"fwd {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
+    if 'epi' in which:
+        d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
+        scr = torch.zeros(((B * Ho * Ho + 255) // 256) * 2 * cout, device=DEV)
+        res = ops.padded(B, Ho, Ho, cout, DEV); ops.interior(res).normal_()
+        fns = [lambda: ops.conv_igemm(d, x, wb, out), lambda: ops.conv_igemm(d, x, wb, out, residual=res),
+               lambda: ops.conv_igemm(d, x, wb, out, bn_scratch=scr),
+               lambda: ops.conv_igemm(d, x, wb, out, residual=res, bn_scratch=scr)]
+        ts = [[], [], [], []]
+        for rnd in range(3):
+            for i in (2, 0, 3, 1):
+                ts[i].append(timeit(fns[i]))
+        line += "  ".join(f"{n} {min(t)*1e6:.0f}/{max(t)*1e6:.0f}us" for n, t in zip(("plain", "+res", "+stats", "+both"), ts))
     if 'dgrad' in which:
         ds = ops.conv_dgrad_descs(B, H, H, cin, cout, k, st)
         t = timeit(lambda: [ops.conv_igemm(d, g, wd, gx) for d in ds]); line += f"dgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "

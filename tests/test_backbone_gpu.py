@@ -129,12 +129,12 @@ def test_conv_epilogue_bn_statistics(B, H, W, cin, cout, k, stride, res):
     d = ops.conv_fwd_desc(B, H, W, cin, cout, k, stride)
     out_a, out_b = ops.padded(B, Ho, Wo, cout, DEV), ops.padded(B, Ho, Wo, cout, DEV)
     scratch = torch.zeros(ops.BN_SLOTS * 2 * cout, device=DEV)
+    partials = torch.full((((B * Ho * Wo + 255) // 256) * 2 * cout,), float("nan"), device=DEV)
     ops.conv_igemm(d, xp, wb, out_a, residual=rp)
-    ops.conv_igemm(d, xp, wb, out_b, residual=rp, bn_scratch=scratch)
+    ops.conv_igemm(d, xp, wb, out_b, residual=rp, bn_scratch=partials)
     assert torch.equal(out_a, out_b)
     mean_f, rstd_f = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
-    ops.bn_finalize(out_b, scratch, mean_f, rstd_f)
-    assert scratch.abs().max().item() == 0
+    ops.bn_finalize(out_b, partials, mean_f, rstd_f)
     mean_r, rstd_r = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
     ops.bn_stats(out_a, scratch, mean_r, rstd_r)
     np.testing.assert_allclose(mean_f.cpu().numpy(), mean_r.cpu().numpy(), rtol=1e-4, atol=1e-5)

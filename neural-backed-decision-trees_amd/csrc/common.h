@@ -105,6 +105,20 @@ int wgrad_dma(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw
 int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
                    float* stats, int M, hipStream_t st);
 
+// conv_halo.hip: 3x3 stride-1 kernel with an LDS-resident halo tile (preferred when applicable)
+struct HaloGeom {
+  int ib, rb;          // images per block, rows per image per block  (ib*rb*gw == 256)
+  int hw2;             // gw + 2
+  int himg;            // (rb+2) * (gw+2): halo pixels per image
+  int hp;              // ib * himg
+  int a_instr;         // ceil(hp*4 / 64) wave-instructions per halo tile (wave w issues ids w, w+4, ..)
+  int a_bytes;         // a_instr * 1024
+  int blocks_per_img;  // gh / rb when ib == 1
+};
+bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
+int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
+                 const void* res, float* stats, int M, hipStream_t st);
+
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {

@@ -253,7 +253,14 @@ static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* 
   // default: v2 (LDS-DMA 3-stage pipeline, conv_dma.hip); NBDT_IGEMM_V1=1 keeps the register-staged
   // kernel below for A/B measurements
   static const bool use_v1 = getenv("NBDT_IGEMM_V1") != nullptr;
-  if (!use_v1) return nbdt::conv_igemm_dma(d, in, w, out, p.res, bn_scratch, p.M, st);
+  if (!use_v1) {
+    // dense 3x3 / stride-1 convs whose pixel tiles are whole rows / images: LDS-resident halo tile
+    static const bool no_halo = getenv("NBDT_NO_HALO") != nullptr;
+    nbdt::HaloGeom hg;
+    if (!no_halo && nbdt::conv_halo_applicable(d, p.M, &hg))
+      return nbdt::conv3x3_halo(d, hg, in, w, out, p.res, bn_scratch, p.M, st);
+    return nbdt::conv_igemm_dma(d, in, w, out, p.res, bn_scratch, p.M, st);
+  }
   NBDT_REQUIRE(bn_scratch == nullptr, "fused BN statistics need the LDS-DMA kernel (unset NBDT_IGEMM_V1)");
   const int nt32 = d->cout / 32;
   if (nt32 % 5 == 0) return launch<5>(p, st);

@@ -1,0 +1,179 @@
+// Shared pieces of the LDS-DMA implicit-GEMM kernels (conv_dma.hip, conv_halo.hip).
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+
+using namespace nbdt;
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+using nbdt::u32x4_t;
+
+namespace nbdt {
+struct ConvDmaParams {
+  nbdt_conv_desc d;
+  const bf16_t* in;
+  const bf16_t* w;
+  bf16_t* out;
+  const bf16_t* res;
+  float* stats;        // nullable: [m_blocks][2][cout] per-pixel-tile partial sum / sum of squares of the output
+  int M, n_blocks, m_blocks, per_xcd;
+  int debug;           // NBDT_IGEMM_DEBUG: timing experiments only (1: no DMA, 2: no waits/barriers, 4: no MFMA)
+};
+}  // namespace nbdt
+
+constexpr int BM = 256;
+constexpr int BK = 32;
+constexpr int NSTAGE = 3;
+
+__device__ __forceinline__ int lds_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ int pix_offset(int m, int gh, int gw, int bs, int hs, int ws, int base) {
+  const int j = m % gw;
+  const int t = m / gw;
+  const int i = t % gh;
+  const int b = t / gh;
+  return b * bs + i * hs + j * ws + base;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the DMA kernels; `ring_bytes` = LDS bytes the caller owns (>= what it needs).
+template <int NT, bool HAS_RES, bool STATS>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
+                                              unsigned char* smem, int m0, int n0, int m_blk, int wave, int lane,
+                                              int tid) {
+  constexpr int BN = 32 * NT;
+  const nbdt_conv_desc& d = p.d;
+  const int frag_row = lane & 31;
+  const int frag_half = lane >> 5;
+  // ---- epilogue through LDS.  The accumulator layout (lane = pixel, regs = 4 consecutive couts) would
+  // give 8-byte stores / residual loads scattered over 32 pixel rows per instruction (the v1 residual
+  // epilogue cost 84 us per launch).  Instead each wave transposes its 32-pixel x BN tile through a
+  // private LDS region: rows of PITCH = 2*BN + 16 bytes (16-B aligned, 2-way at worst for the 8-byte
+  // lane writes), then walks it with a FIXED 8-channel chunk per lane: 16-byte coalesced residual
+  // loads / output stores (20 lanes = one 320-B pixel row), and -- because the chunk is fixed -- the
+  // per-channel sum and sum of squares of the bf16 output fall out of the same pass in registers.  They
+  // feed the next BatchNorm (bn_finalize only), replacing a full re-read of the tensor (bn_stats_kernel).
+  constexpr int PITCH = 2 * BN + 16;
+  constexpr int REGION = 32 * PITCH;
+  constexpr int NCH = BN / 8;            // 8-channel chunks per row
+  constexpr int RL = 64 / NCH;           // row lanes: lanes [0, RL*NCH) are active in the row walk
+  constexpr int ROW_ITERS = (32 + RL - 1) / RL;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();          // every wave is done with the K ring
+  asm volatile("" ::: "memory");
+  unsigned char* region = smem + wave * REGION;
+  int* row_off = (int*)(smem + 4 * REGION) + wave * 64;      // element offset of each of the wave's 64 pixels
+  float* blk_stats = (float*)(smem + 4 * REGION + 4 * 64 * 4);  // [2][BN]
+  {
+    const int m = m0 + wave * 64 + lane;
+    row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
+    if (STATS) {
+      for (int i = tid; i < 2 * BN; i += 256) blk_stats[i] = 0.f;
+      __syncthreads();   // block-uniform: zeroed before any wave's atomics
+    }
+  }
+  const int ch = lane % NCH, rl = lane / NCH;
+  const bool walker = rl < RL;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    if (HAS_RES) {  // (1) residual rows -> LDS, coalesced; all loads issued before the first LDS write
+      if (walker) {   // (unconditional loads: rows past M re-read row 0, their results are never stored)
+        u32x4_t rv[ROW_ITERS];
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          int r = rl + it * RL;
+          r = r < 32 ? r : 31;
+          int o = row_off[tm * 32 + r];
+          o = o >= 0 ? o : p.d.out_base + n0;
+          rv[it] = *(const u32x4_t*)(p.res + o + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          const int r = rl + it * RL;
+          if (r < 32) *(u32x4_t*)(region + r * PITCH + ch * 16) = rv[it];
+        }
+      }
+    }
+    // (2) accumulators (+ residual, fp32, single rounding) -> bf16 -> LDS at [pixel][cout]
+    unsigned char* myrow = region + frag_row * PITCH + frag_half * 8;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v0 = acc[tn][tm][4 * q + 0], v1 = acc[tn][tm][4 * q + 1];
+        float v2 = acc[tn][tm][4 * q + 2], v3 = acc[tn][tm][4 * q + 3];
+        unsigned char* at = myrow + (tn * 32 + q * 8) * 2;
+        if (HAS_RES) {
+          const u32x2 r = *(const u32x2*)at;
+          v0 += __uint_as_float(r[0] << 16);
+          v1 += __uint_as_float(r[0] & 0xffff0000u);
+          v2 += __uint_as_float(r[1] << 16);
+          v3 += __uint_as_float(r[1] & 0xffff0000u);
+        }
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v0, v1);
+        pk[1] = pack_bf16x2(v2, v3);
+        *(u32x2*)at = pk;
+      }
+    // (3) walk the rows: coalesced 16-byte stores (+ statistics of the rounded values)
+    if (walker)
+#pragma unroll
+      for (int it = 0; it < ROW_ITERS; ++it) {
+        const int r = rl + it * RL;
+        if (r < 32) {
+          const int o = row_off[tm * 32 + r];
+          if (o >= 0) {
+            const u32x4_t v = *(const u32x4_t*)(region + r * PITCH + ch * 16);
+            *(u32x4_t*)(p.out + o + ch * 8) = v;
+            if (STATS) {
+              float f[8];
+              unpack8(v, f);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+            }
+          }
+        }
+      }
+  }
+  if (STATS) {
+    if (walker)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        atomicAdd(blk_stats + ch * 8 + i, s1[i]);
+        atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
+      }
+    __syncthreads();
+    // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost
+    // more than the separate statistics pass they replace); nbdt_bn_finalize folds the rows
+    float* part = p.stats + (size_t)m_blk * 2 * d.cout;
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, c = i - which * BN;
+      part[(size_t)which * d.cout + n0 + c] = blk_stats[i];
+    }
+  }
+}
+
+template <int NT>
+constexpr int conv_epilogue_lds_bytes() {
+  return 4 * 32 * (2 * 32 * NT + 16) + 4 * 64 * 4 + 2 * 32 * NT * 4;
+}

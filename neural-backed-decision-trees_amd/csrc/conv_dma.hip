@@ -16,54 +16,7 @@
 // One wave-instruction = 16 rows x 64 B.  Each lane's pixel/weight-row offsets are fixed for the whole
 // block, so a DMA costs one 64-bit add.  The per-tap input offset lives in lane `tap` of a VGPR and is
 // fetched with v_readlane (no scalar memory load inside the pipeline).
-#include "common.h"
-#include <stdlib.h>
-
-using namespace nbdt;
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-using nbdt::u32x4_t;
-
-namespace nbdt {
-struct ConvDmaParams {
-  nbdt_conv_desc d;
-  const bf16_t* in;
-  const bf16_t* w;
-  bf16_t* out;
-  const bf16_t* res;
-  float* stats;        // nullable: [m_blocks][2][cout] per-pixel-tile partial sum / sum of squares of the output
-  int M, n_blocks, m_blocks, per_xcd;
-};
-}  // namespace nbdt
-
-constexpr int BM = 256;
-constexpr int BK = 32;
-constexpr int NSTAGE = 3;
-
-__device__ __forceinline__ int lds_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
-
-__device__ __forceinline__ int pix_offset(int m, int gh, int gw, int bs, int hs, int ws, int base) {
-  const int j = m % gw;
-  const int t = m / gw;
-  const int i = t % gh;
-  const int b = t / gh;
-  return b * bs + i * hs + j * ws + base;
-}
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
+#include "conv_common.h"
 
 // fewest DMAs any wave issues per stage: A = 16 instructions (4 per wave), W = BN/16 instructions
 // handed out as {(w+2)%4, +4, ..}
@@ -191,135 +144,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
   advance();
   if (nk > 1) { issue(1, tap, kc); advance(); }
   int slot = 0;
+  const int dbg = __builtin_amdgcn_readfirstlane(p.debug);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(dbg & 2)) {
+      if (t + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
     }
-    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < nk) {
+    if (t + 2 < nk && !(dbg & 1)) {
       int s2 = slot + 2;
       s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
       issue(s2, tap, kc);
       advance();
     }
-    compute(slot);
+    if (!(dbg & 4)) compute(slot);
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
   }
 
-  // ---- epilogue through LDS.  The accumulator layout (lane = pixel, regs = 4 consecutive couts) would
-  // give 8-byte stores / residual loads scattered over 32 pixel rows per instruction (the v1 residual
-  // epilogue cost 84 us per launch).  Instead each wave transposes its 32-pixel x BN tile through a
-  // private LDS region: rows of PITCH = 2*BN + 16 bytes (16-B aligned, 2-way at worst for the 8-byte
-  // lane writes), then walks it with a FIXED 8-channel chunk per lane: 16-byte coalesced residual
-  // loads / output stores (20 lanes = one 320-B pixel row), and -- because the chunk is fixed -- the
-  // per-channel sum and sum of squares of the bf16 output fall out of the same pass in registers.  They
-  // feed the next BatchNorm (bn_finalize only), replacing a full re-read of the tensor (bn_stats_kernel).
-  constexpr int PITCH = 2 * BN + 16;
-  constexpr int REGION = 32 * PITCH;
-  constexpr int NCH = BN / 8;            // 8-channel chunks per row
-  constexpr int RL = 64 / NCH;           // row lanes: lanes [0, RL*NCH) are active in the row walk
-  constexpr int ROW_ITERS = (32 + RL - 1) / RL;
-  static_assert(4 * REGION + 4 * 64 * 4 + 2 * BN * 4 <= NSTAGE * STAGE, "epilogue does not fit in the ring");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();          // every wave is done with the K ring
-  asm volatile("" ::: "memory");
-  unsigned char* region = smem + wave * REGION;
-  int* row_off = (int*)(smem + 4 * REGION) + wave * 64;      // element offset of each of the wave's 64 pixels
-  float* blk_stats = (float*)(smem + 4 * REGION + 4 * 64 * 4);  // [2][BN]
-  {
-    const int m = m0 + wave * 64 + lane;
-    row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
-    if (STATS) {
-      for (int i = tid; i < 2 * BN; i += 256) blk_stats[i] = 0.f;
-      __syncthreads();   // block-uniform: zeroed before any wave's atomics
-    }
-  }
-  const int ch = lane % NCH, rl = lane / NCH;
-  const bool walker = rl < RL;
-  float s1[8], s2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    if (HAS_RES) {  // (1) residual rows -> LDS, coalesced; all loads issued before the first LDS write
-      if (walker) {   // (unconditional loads: rows past M re-read row 0, their results are never stored)
-        u32x4_t rv[ROW_ITERS];
-#pragma unroll
-        for (int it = 0; it < ROW_ITERS; ++it) {
-          int r = rl + it * RL;
-          r = r < 32 ? r : 31;
-          int o = row_off[tm * 32 + r];
-          o = o >= 0 ? o : p.d.out_base + n0;
-          rv[it] = *(const u32x4_t*)(p.res + o + ch * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < ROW_ITERS; ++it) {
-          const int r = rl + it * RL;
-          if (r < 32) *(u32x4_t*)(region + r * PITCH + ch * 16) = rv[it];
-        }
-      }
-    }
-    // (2) accumulators (+ residual, fp32, single rounding) -> bf16 -> LDS at [pixel][cout]
-    unsigned char* myrow = region + frag_row * PITCH + frag_half * 8;
-#pragma unroll
-    for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v0 = acc[tn][tm][4 * q + 0], v1 = acc[tn][tm][4 * q + 1];
-        float v2 = acc[tn][tm][4 * q + 2], v3 = acc[tn][tm][4 * q + 3];
-        unsigned char* at = myrow + (tn * 32 + q * 8) * 2;
-        if (HAS_RES) {
-          const u32x2 r = *(const u32x2*)at;
-          v0 += __uint_as_float(r[0] << 16);
-          v1 += __uint_as_float(r[0] & 0xffff0000u);
-          v2 += __uint_as_float(r[1] << 16);
-          v3 += __uint_as_float(r[1] & 0xffff0000u);
-        }
-        u32x2 pk;
-        pk[0] = pack_bf16x2(v0, v1);
-        pk[1] = pack_bf16x2(v2, v3);
-        *(u32x2*)at = pk;
-      }
-    // (3) walk the rows: coalesced 16-byte stores (+ statistics of the rounded values)
-    if (walker)
-#pragma unroll
-      for (int it = 0; it < ROW_ITERS; ++it) {
-        const int r = rl + it * RL;
-        if (r < 32) {
-          const int o = row_off[tm * 32 + r];
-          if (o >= 0) {
-            const u32x4_t v = *(const u32x4_t*)(region + r * PITCH + ch * 16);
-            *(u32x4_t*)(p.out + o + ch * 8) = v;
-            if (STATS) {
-              float f[8];
-              unpack8(v, f);
-#pragma unroll
-              for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
-            }
-          }
-        }
-      }
-  }
-  if (STATS) {
-    if (walker)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        atomicAdd(blk_stats + ch * 8 + i, s1[i]);
-        atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
-      }
-    __syncthreads();
-    // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost
-    // more than the separate statistics pass they replace); nbdt_bn_finalize folds the rows
-    float* part = p.stats + (size_t)m_blk * 2 * d.cout;
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int which = i / BN, c = i - which * BN;
-      part[(size_t)which * d.cout + n0 + c] = blk_stats[i];
-    }
-  }
+  static_assert(conv_epilogue_lds_bytes<NT>() <= NSTAGE * STAGE, "epilogue does not fit in the ring");
+  conv_epilogue<NT, HAS_RES, STATS>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
 }
 
 namespace nbdt {
@@ -361,6 +208,8 @@ int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void*
   p.res = (const bf16_t*)res;
   p.stats = stats;
   p.M = M;
+  static const int dbg = getenv("NBDT_IGEMM_DEBUG") ? atoi(getenv("NBDT_IGEMM_DEBUG")) : 0;
+  p.debug = dbg;
   const int nt32 = d->cout / 32;
   if (nt32 % 5 == 0) return launch_dma<5>(p, st);
   if (nt32 % 4 == 0) return launch_dma<4>(p, st);

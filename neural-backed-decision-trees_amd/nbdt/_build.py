@@ -24,6 +24,7 @@ FLAGS = {
     "rules.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "conv.hip": ["-munsafe-fp-atomics"],
     "conv_dma.hip": ["-munsafe-fp-atomics"],
+    "conv_halo.hip": ["-munsafe-fp-atomics"],
     "wgrad.hip": ["-munsafe-fp-atomics"],
     "wgrad_dma.hip": ["-munsafe-fp-atomics"],
     "bn.hip": ["-munsafe-fp-atomics"],

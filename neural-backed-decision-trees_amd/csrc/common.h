@@ -101,6 +101,10 @@ __device__ __forceinline__ int pad_offset(const PadGeom& g, int p) {
 // wgrad_dma.hip: LDS-DMA + transpose-read weight-gradient kernel (default path of nbdt_conv_wgrad)
 int wgrad_dma(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
 
+// wgrad_taps.hip: all-nine-taps weight-gradient kernel for dense 3x3 stride-1 convs (preferred)
+bool wgrad_taps_applicable(const nbdt_wgrad_desc* d);
+int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
+
 // conv_dma.hip: LDS-DMA pipelined implicit GEMM (default path of nbdt_conv_igemm)
 int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
                    float* stats, int M, hipStream_t st);

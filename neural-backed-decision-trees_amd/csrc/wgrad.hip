@@ -262,7 +262,11 @@ extern "C" int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const vo
   // default: v3 (LDS-DMA + transpose reads, wgrad_dma.hip).  NBDT_WGRAD_V2=1 selects the
   // register-staged v2 kernel below (kept for A/B measurements; needs gw % 4 == 0).
   static const bool use_v2 = getenv("NBDT_WGRAD_V2") != nullptr;
-  if (!use_v2) return nbdt::wgrad_dma(d, x, gy, dw, (hipStream_t)stream);
+  if (!use_v2) {
+    static const bool no_taps = getenv("NBDT_NO_TAPS") != nullptr;
+    if (!no_taps && nbdt::wgrad_taps_applicable(d)) return nbdt::wgrad_taps(d, x, gy, dw, (hipStream_t)stream);
+    return nbdt::wgrad_dma(d, x, gy, dw, (hipStream_t)stream);
+  }
   NBDT_REQUIRE(d->gw % 4 == 0, "v2 wgrad: pixel grid width must be a multiple of 4");
   WgradParams p;
   p.d = *d;

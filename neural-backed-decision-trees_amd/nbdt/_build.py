@@ -27,6 +27,7 @@ FLAGS = {
     "conv_halo.hip": ["-munsafe-fp-atomics"],
     "wgrad.hip": ["-munsafe-fp-atomics"],
     "wgrad_dma.hip": ["-munsafe-fp-atomics"],
+    "wgrad_taps.hip": ["-munsafe-fp-atomics"],
     "bn.hip": ["-munsafe-fp-atomics"],
     "misc.hip": ["-munsafe-fp-atomics"],
 }

@@ -120,6 +120,14 @@ int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void
 int nbdt_conv_igemm_stats(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                           const void* residual, float* bn_partials, void* stream);
 
+/* data-gradient launch whose output is dL/d(relu(bn(x))): the epilogue also reads x (the BatchNorm's
+ * forward input, same geometry as `out`) and writes per-tile partial sums of g' and g'*xhat, g' = out *
+ * [bn(x) > 0] -- the reductions of the BatchNorm backward (nbdt_bn_bwd_fold folds them; replaces
+ * nbdt_bn_bwd_reduce and one full re-read of the gradient tensor). */
+int nbdt_conv_igemm_bnbwd(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                          const void* bn_x, const float* save_mean, const float* save_rstd,
+                          const float* gamma, const float* beta, float* bn_partials, void* stream);
+
 /* weight gradient (replaces cuDNN wgrad): dw[cout][w_ntaps][cin] fp32 += sum over the pixel grid
  * of gy[pix_g(m)][co] * x[pix_x(m) + tap_off[t]][ci]; split over pixels with fp32 atomics, so dw
  * must be zeroed (or hold the running .grad) before the call. */
@@ -140,6 +148,11 @@ int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const void* gy, flo
  * wd[cin][taps][cout] with the tap order reversed (wd[ci][t][co] = w[co][taps-1-t][ci]) */
 int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, void* w_bf16,
                      void* wd_bf16, void* stream);
+
+/* the dgrad copies of EVERY conv layer in one launch: table (device, int64 [n_layers][6]) rows are
+ * {src offset in flat, dst offset in wd_flat, cout, taps, cin, first work index}; total = sum of numels */
+int nbdt_weight_prep_batched(const float* flat, const int64_t* table, int32_t n_layers, int64_t total,
+                             void* wd_flat, void* stream);
 
 /* ------------------------------------------------------------------ backbone: batch-norm / elementwise
  * Replaces nn.BatchNorm2d (train mode, eps 1e-5, momentum 0.1) + F.relu + residual adds
@@ -169,6 +182,9 @@ int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float
                        const float* save_rstd, const float* gamma, const float* beta, int32_t relu,
                        int32_t B, int32_t H, int32_t W, int32_t C, float* scratch, float* dsum,
                        float* dgamma, float* dbeta, void* stream);
+/* fold the partials of nbdt_conv_igemm_bnbwd into dsum[2][C]; dbeta += dsum[0], dgamma += dsum[1] */
+int nbdt_bn_bwd_fold(int32_t B, int32_t H, int32_t W, int32_t C, const float* bn_partials, float* dsum,
+                     float* dgamma, float* dbeta, void* stream);
 /* backward, pass 2: gx = gamma*rstd*(gy' - (dsum0 + xhat*dsum1)/N) [+ gx_add];
  * g_resid (nullable) receives gy' (the gradient of the residual input). */
 int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float* save_mean,

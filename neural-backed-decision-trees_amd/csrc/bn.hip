@@ -371,6 +371,51 @@ __global__ __launch_bounds__(1024) void bn_fold_partials_kernel(const float* __r
   }
 }
 
+// backward twin of bn_fold_partials_kernel: rows of {sum g', sum g'*xhat} -> dsum (+= dbeta / dgamma)
+__global__ __launch_bounds__(1024) void bn_bwd_fold_partials_kernel(const float* __restrict__ part, int rows, int C,
+                                                                    float* __restrict__ dsum,
+                                                                    float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta) {
+  __shared__ float red[2][32][33];
+  const int cl = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+  if (c < C) {
+    int r = rs;
+    for (; r + 32 < rows; r += 64) {
+      s0 += part[((size_t)r * 2 + 0) * C + c];         q0 += part[((size_t)r * 2 + 1) * C + c];
+      s1 += part[((size_t)(r + 32) * 2 + 0) * C + c];  q1 += part[((size_t)(r + 32) * 2 + 1) * C + c];
+    }
+    for (; r < rows; r += 32) {
+      s0 += part[((size_t)r * 2 + 0) * C + c];
+      q0 += part[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][rs][cl] = s0 + s1;
+  red[1][rs][cl] = q0 + q1;
+  __syncthreads();
+  if (rs == 0 && c < C) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < 32; ++k) { a += red[0][k][cl]; b += red[1][k][cl]; }
+    dsum[c] = a;
+    dsum[C + c] = b;
+    if (dbeta) dbeta[c] += a;
+    if (dgamma) dgamma[c] += b;
+  }
+}
+
+extern "C" int nbdt_bn_bwd_fold(int32_t B, int32_t H, int32_t W, int32_t C, const float* bn_partials, float* dsum,
+                                float* dgamma, float* dbeta, void* stream) {
+  NBDT_REQUIRE(bn_partials && dsum, "null argument");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  const int rows = (int)(((long long)B * H * W + 255) / 256);
+  hipLaunchKernelGGL(bn_bwd_fold_partials_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, bn_partials,
+                     rows, C, dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
 extern "C" int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
                                 float* running_mean, float* running_var, const float* partials, float* save_mean,
                                 float* save_rstd, void* stream) {

@@ -106,8 +106,12 @@ bool wgrad_taps_applicable(const nbdt_wgrad_desc* d);
 int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
 
 // conv_dma.hip: LDS-DMA pipelined implicit GEMM (default path of nbdt_conv_igemm)
+struct BnBwdArgs {   // the BatchNorm whose input gradient a dgrad launch produces (epilogue STATS mode 2)
+  const void* x;
+  const float *mean, *rstd, *gamma, *beta;
+};
 int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
-                   float* stats, int M, hipStream_t st);
+                   float* stats, const BnBwdArgs* bn, int M, hipStream_t st);
 
 // conv_halo.hip: 3x3 stride-1 kernel with an LDS-resident halo tile (preferred when applicable)
 struct HaloGeom {
@@ -120,8 +124,9 @@ struct HaloGeom {
   int blocks_per_img;  // gh / rb when ib == 1
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
+struct BnBwdArgs;
 int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
-                 const void* res, float* stats, int M, hipStream_t st);
+                 const void* res, float* stats, const BnBwdArgs* bn, int M, hipStream_t st);
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 

@@ -227,7 +227,7 @@ static int launch(ConvParams& p, hipStream_t st) {
 }
 
 static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* residual,
-                           float* bn_scratch, void* stream) {
+                           float* bn_scratch, void* stream, const nbdt::BnBwdArgs* bn = nullptr) {
   NBDT_REQUIRE(d && in && w && out, "null argument");
   NBDT_REQUIRE(d->cin > 0 && d->cin % 32 == 0, "cin must be a multiple of 32");
   NBDT_REQUIRE(d->cout > 0 && d->cout % 32 == 0, "cout must be a multiple of 32");
@@ -258,8 +258,8 @@ static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* 
     static const bool no_halo = getenv("NBDT_NO_HALO") != nullptr;
     nbdt::HaloGeom hg;
     if (!no_halo && nbdt::conv_halo_applicable(d, p.M, &hg))
-      return nbdt::conv3x3_halo(d, hg, in, w, out, p.res, bn_scratch, p.M, st);
-    return nbdt::conv_igemm_dma(d, in, w, out, p.res, bn_scratch, p.M, st);
+      return nbdt::conv3x3_halo(d, hg, in, w, out, p.res, bn_scratch, bn, p.M, st);
+    return nbdt::conv_igemm_dma(d, in, w, out, p.res, bn_scratch, bn, p.M, st);
   }
   NBDT_REQUIRE(bn_scratch == nullptr, "fused BN statistics need the LDS-DMA kernel (unset NBDT_IGEMM_V1)");
   const int nt32 = d->cout / 32;
@@ -281,6 +281,15 @@ extern "C" int nbdt_conv_igemm_stats(const nbdt_conv_desc* d, const void* in, co
   return conv_igemm_impl(d, in, w, out, residual, bn_scratch, stream);
 }
 
+extern "C" int nbdt_conv_igemm_bnbwd(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                                     const void* bn_x, const float* save_mean, const float* save_rstd,
+                                     const float* gamma, const float* beta, float* bn_partials, void* stream) {
+  NBDT_REQUIRE(bn_x && save_mean && save_rstd && gamma && beta && bn_partials, "null BatchNorm argument");
+  NBDT_REQUIRE(d && !d->accumulate, "fused BatchNorm-backward sums are for plain outputs");
+  nbdt::BnBwdArgs bn{bn_x, save_mean, save_rstd, gamma, beta};
+  return conv_igemm_impl(d, in, w, out, nullptr, bn_partials, stream, &bn);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight prep: fp32 master [cout][taps][cin] -> bf16 same order (+ optional dgrad copy
 // wd[cin][taps][cout], tap order reversed).  Tiny, memory-bound.
@@ -299,6 +308,42 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
       wd[((int64_t)ci * taps + (taps - 1 - t)) * cout + co] = v;
     }
   }
+}
+
+// All conv layers in ONE launch (the per-layer form costs 30 launches x 17 us per optimizer step):
+// table[l] = {src element offset in the flat fp32 buffer, dst element offset in wd_flat, cout, taps, cin,
+// first flat work index of the layer}; work index e in [prefix[l], prefix[l+1]) is element e-prefix[l] of
+// layer l in [cout][taps][cin] order.
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const float* __restrict__ flat,
+                                                                  const long long* __restrict__ table, int n_layers,
+                                                                  long long total, bf16_t* __restrict__ wd_flat) {
+  __shared__ long long tab[64 * 6];
+  for (int i = threadIdx.x; i < n_layers * 6; i += 256) tab[i] = table[i];
+  __syncthreads();
+  int l = 0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    while (l + 1 < n_layers && e >= tab[(l + 1) * 6 + 5]) ++l;   // e is increasing per thread
+    const long long* T = tab + l * 6;
+    const long long i = e - T[5];
+    const int cout = (int)T[2], taps = (int)T[3], cin = (int)T[4];
+    const int ci = (int)(i % cin);
+    const long long r = i / cin;
+    const int t = (int)(r % taps);
+    const int co = (int)(r / taps);
+    wd_flat[T[1] + ((long long)ci * taps + (taps - 1 - t)) * cout + co] = f32_to_bf16(flat[T[0] + i]);
+  }
+}
+
+extern "C" int nbdt_weight_prep_batched(const float* flat, const int64_t* table, int32_t n_layers, int64_t total,
+                                        void* wd_flat, void* stream) {
+  NBDT_REQUIRE(flat && table && wd_flat, "null argument");
+  NBDT_REQUIRE(n_layers > 0 && n_layers <= 64 && total > 0, "bad layer table");
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(weight_prep_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flat,
+                     (const long long*)table, n_layers, (long long)total, (bf16_t*)wd_flat);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
 }
 
 extern "C" int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, void* w_bf16,

@@ -17,7 +17,10 @@ struct ConvDmaParams {
   const bf16_t* w;
   bf16_t* out;
   const bf16_t* res;
-  float* stats;        // nullable: [m_blocks][2][cout] per-pixel-tile partial sum / sum of squares of the output
+  float* stats;        // nullable: [m_blocks][2][cout] per-pixel-tile partial sums (see STATS modes below)
+  // STATS == 2 only: the BatchNorm whose input gradient this launch produces (x = its forward input)
+  const bf16_t* bn_x;
+  const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
   int M, n_blocks, m_blocks, per_xcd;
   int debug;           // NBDT_IGEMM_DEBUG: timing experiments only (1: no DMA, 2: no waits/barriers, 4: no MFMA)
 };
@@ -52,8 +55,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Epilogue shared by the DMA kernels; `ring_bytes` = LDS bytes the caller owns (>= what it needs).
-template <int NT, bool HAS_RES, bool STATS>
+// Epilogue shared by the DMA kernels.  STATS modes (the per-tile partials go to p.stats):
+//   0  none
+//   1  forward : sum(out), sum(out^2)                  -> batch statistics of the NEXT BatchNorm
+//   2  backward: out = dL/d(relu(bn(x))); with g' = out * [bn(x) > 0]:  sum(g'), sum(g' * xhat)
+//                -> dbeta / dgamma sums of the BatchNorm being differentiated (replaces bn_bwd_reduce:
+//                   the gradient tensor is not re-read, x is read once, coalesced, right here)
+template <int NT, bool HAS_RES, int STATS>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
                                               unsigned char* smem, int m0, int n0, int m_blk, int wave, int lane,
                                               int tid) {
@@ -93,6 +101,17 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   float s1[8], s2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+  float bmu[8], brs[8], bsc[8], bsh[8];   // STATS == 2: this lane's 8 channels of the BatchNorm
+  if (STATS == 2 && walker) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = n0 + ch * 8 + i;
+      bmu[i] = p.bn_mean[c];
+      brs[i] = p.bn_rstd[c];
+      bsc[i] = p.bn_gamma[c] * brs[i];
+      bsh[i] = p.bn_beta[c] - bmu[i] * bsc[i];
+    }
+  }
 
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
@@ -136,7 +155,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
         *(u32x2*)at = pk;
       }
     // (3) walk the rows: coalesced 16-byte stores (+ statistics of the rounded values)
-    if (walker)
+    if (walker) {
+      u32x4_t xv[STATS == 2 ? ROW_ITERS : 1];
+      if (STATS == 2) {   // the BatchNorm input rows, all loads in flight before the first use
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          int r = rl + it * RL;
+          r = r < 32 ? r : 31;
+          int o = row_off[tm * 32 + r];
+          o = o >= 0 ? o : p.d.out_base + n0;
+          xv[it] = *(const u32x4_t*)(p.bn_x + o + ch * 8);
+        }
+      }
 #pragma unroll
       for (int it = 0; it < ROW_ITERS; ++it) {
         const int r = rl + it * RL;
@@ -145,15 +175,27 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
           if (o >= 0) {
             const u32x4_t v = *(const u32x4_t*)(region + r * PITCH + ch * 16);
             *(u32x4_t*)(p.out + o + ch * 8) = v;
-            if (STATS) {
+            if (STATS == 1) {
               float f[8];
               unpack8(v, f);
 #pragma unroll
               for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
             }
+            if (STATS == 2) {
+              float f[8], fx[8];
+              unpack8(v, f);
+              unpack8(xv[it], fx);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float gg = (fx[i] * bsc[i] + bsh[i]) > 0.f ? f[i] : 0.f;
+                s1[i] += gg;
+                s2[i] += gg * ((fx[i] - bmu[i]) * brs[i]);
+              }
+            }
           }
         }
       }
+    }
   }
   if (STATS) {
     if (walker)

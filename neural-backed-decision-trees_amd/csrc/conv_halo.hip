@@ -32,7 +32,7 @@ constexpr int min_w_dma_h(int w_instr) {
 }
 
 
-template <int NT, bool HAS_RES, bool STATS>
+template <int NT, bool HAS_RES, int STATS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParams p, nbdt::HaloGeom hg) {
   constexpr int BN = 32 * NT;
   constexpr int W_BYTES = BN * BK * 2;
@@ -235,14 +235,15 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
 #define NBDT_ATTR(R, S)                                                                                     \
   NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>),         \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
-    NBDT_ATTR(true, true); NBDT_ATTR(true, false); NBDT_ATTR(false, true); NBDT_ATTR(false, false);
+    NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
 #undef NBDT_ATTR
     attr_bytes = shmem;
   }
   const dim3 grid(p.per_xcd * 8), blk(256);
 #define NBDT_GO(R, S) hipLaunchKernelGGL((conv3x3_halo_kernel<NT, R, S>), grid, blk, shmem, st, p, hg)
-  if (p.res != nullptr) { if (p.stats) NBDT_GO(true, true); else NBDT_GO(true, false); }
-  else { if (p.stats) NBDT_GO(false, true); else NBDT_GO(false, false); }
+  if (p.bn_x != nullptr) NBDT_GO(false, 2);
+  else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
+  else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
 #undef NBDT_GO
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
@@ -285,7 +286,7 @@ bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
 }
 
 int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
-                 const void* res, float* stats, int M, hipStream_t st) {
+                 const void* res, float* stats, const BnBwdArgs* bn, int M, hipStream_t st) {
   ConvDmaParams p;
   p.d = *d;
   p.in = (const bf16_t*)in;
@@ -293,6 +294,9 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.out = (bf16_t*)out;
   p.res = (const bf16_t*)res;
   p.stats = stats;
+  p.bn_x = bn ? (const bf16_t*)bn->x : nullptr;
+  p.bn_mean = bn ? bn->mean : nullptr; p.bn_rstd = bn ? bn->rstd : nullptr;
+  p.bn_gamma = bn ? bn->gamma : nullptr; p.bn_beta = bn ? bn->beta : nullptr;
   p.M = M;
   p.debug = 0;
   const int nt32 = d->cout / 32;

@@ -117,20 +117,24 @@ class Conv:
             )
         return self._plans[key]
 
-    def refresh_dgrad_weights(self):
-        if self.wd is None:
-            self.wd = torch.empty((self.cin, self.taps, self.cout), dtype=torch.bfloat16,
-                                  device=self.store.device)
-        ops.weight_prep(self.store.p(self.name), self.cout, self.taps, self.cin, None, self.wd)
+    def numel(self):
+        return self.cout * self.taps * self.cin
 
     def forward(self, x, out, residual=None, bn_scratch=None):
         B, Hp, Wp, _ = x.shape
         ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, residual, bn_scratch)
 
-    def backward_data(self, gout, gin, accumulate=False):
+    def backward_data(self, gout, gin, accumulate=False, bn=None, bn_x=None, partials=None):
+        """bn/bn_x/partials: `gin` is dL/d(relu(bn(bn_x))) -- also emit that BatchNorm's backward sums
+        (single-launch stride-1 dgrads only)."""
         B, Hp, Wp, _ = gin.shape
         plan = self.plan(B, Hp - 2, Wp - 2)
-        for d in (plan[2] if accumulate else plan[1]):
+        descs = plan[2] if accumulate else plan[1]
+        if bn is not None:
+            assert len(descs) == 1 and not accumulate
+            ops.conv_igemm_bnbwd(descs[0], gout, self.wd, gin, bn_x, bn.mean, bn.rstd, bn.gamma, bn.beta, partials)
+            return
+        for d in descs:
             ops.conv_igemm(d, gout, self.wd, gin)
 
     def backward_weight(self, x, gout):
@@ -177,6 +181,11 @@ class BatchNorm:
 
     def apply(self, x, y, relu=True, residual=None):
         ops.bn_apply(x, self.mean, self.rstd, self.gamma, self.beta, y, relu=relu, residual=residual)
+
+    def backward_fused(self, gy, x, gx, partials, gx_add=None):
+        """Backward of relu(bn(x)) when the dgrad that produced gy already wrote the reduction partials."""
+        ops.bn_bwd_fused(gy, x, self.mean, self.rstd, self.gamma, self.beta, partials, self.dsum,
+                         self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, gx_add=gx_add)
 
     def backward(self, gy, y, x, gx, relu=True, gx_add=None, g_resid=None):
         """y=None: recompute the ReLU mask from x (valid when apply() had no residual)."""
@@ -234,11 +243,21 @@ class _Engine:
 
     def finalize(self):
         self.store.finalize()
+        # one flat buffer for every conv's data-gradient weight copy + the layer table of the batched
+        # transpose kernel (one launch per optimizer step instead of one per layer)
+        total = sum(c.numel() for c in self.convs)
+        self._wd_flat = torch.empty(total, dtype=torch.bfloat16, device=self.device)
+        rows, off = [], 0
+        for c in self.convs:
+            rows.append([self.store.entries[c.name][0], off, c.cout, c.taps, c.cin, off])
+            c.wd = self._wd_flat[off:off + c.numel()].view(c.cin, c.taps, c.cout)
+            off += c.numel()
+        self._wd_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self._wd_total = total
         self.refresh_derived_weights()
 
     def refresh_derived_weights(self):
-        for c in self.convs:
-            c.refresh_dgrad_weights()
+        ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
         """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights."""
@@ -425,10 +444,21 @@ class WRNEngine(_Engine):
             toggle ^= 1
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
+            fuse = self.fuse_stats
             u["conv2"].backward_weight(a2, g)
-            u["conv2"].backward_data(g, ga2)
-            u["bn2"].backward(ga2, None, t, gt, relu=True)       # mask recomputed from t: a2 not re-read
+            if fuse:   # the dgrad epilogue also produces bn2's backward sums (ga2 is not re-read for them)
+                u["conv2"].backward_data(g, ga2, bn=u["bn2"], bn_x=t, partials=self.partials(t))
+                u["bn2"].backward_fused(ga2, t, gt, self.partials(t))
+            else:
+                u["conv2"].backward_data(g, ga2)
+                u["bn2"].backward(ga2, None, t, gt, relu=True)   # mask recomputed from t: a2 not re-read
             u["conv1"].backward_weight(a1, gt)
+            if fuse and u["idconv"] is None:
+                x_in = u["x_in"]
+                u["conv1"].backward_data(gt, ga1, bn=u["bn1"], bn_x=x_in, partials=self.partials(x_in))
+                u["bn1"].backward_fused(ga1, x_in, g_in, self.partials(x_in), gx_add=g)
+                g, h, w = g_in, hi, wi
+                continue
             u["conv1"].backward_data(gt, ga1)
             if u["idconv"] is not None:
                 u["idconv"].backward_weight(a1, g)

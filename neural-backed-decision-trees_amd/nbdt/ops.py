@@ -200,6 +200,28 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
         ev[1].record()
 
 
+def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, partials):
+    """dgrad launch that also produces the BatchNorm-backward sums of (out, bn_x) as per-tile partials."""
+    ev = None
+    if _timer is not None:
+        flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
+        ev = _timer.bracket("conv_igemm", flops, inp.device)
+        ev[0].record()
+    check(lib().nbdt_conv_igemm_bnbwd(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(bn_x), ptr(mean),
+                                      ptr(rstd), ptr(gamma), ptr(beta), ptr(partials), stream_ptr(inp.device)))
+    if ev is not None:
+        ev[1].record()
+
+
+def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, gx, gx_add=None):
+    """BatchNorm(+ReLU) backward when the producing dgrad already left the reduction partials."""
+    B, H, W, C = _dims(x)
+    st = stream_ptr(x.device)
+    check(lib().nbdt_bn_bwd_fold(B, H, W, C, ptr(partials), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
+    check(lib().nbdt_bn_bwd_apply(ptr(gy), None, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                  ptr(dsum), ptr(gx_add), 1, B, H, W, C, ptr(gx), None, st))
+
+
 def conv_wgrad(desc, x, gy, dw):
     ev = None
     if _timer is not None:
@@ -214,6 +236,11 @@ def conv_wgrad(desc, x, gy, dw):
 def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):
     check(lib().nbdt_weight_prep(ptr(w_fp32), cout, taps, cin, ptr(w_bf16), ptr(wd_bf16),
                                  stream_ptr(w_fp32.device)))
+
+
+def weight_prep_batched(flat, table, n_layers, total, wd_flat):
+    check(lib().nbdt_weight_prep_batched(ptr(flat), ptr(table), n_layers, total, ptr(wd_flat),
+                                         stream_ptr(flat.device)))
 
 
 def _dims(t):

@@ -141,6 +141,38 @@ def test_conv_epilogue_bn_statistics(B, H, W, cin, cout, k, stride, res):
     np.testing.assert_allclose(rstd_f.cpu().numpy(), rstd_r.cpu().numpy(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 8, 8, 160, 160), (2, 16, 16, 160, 32), (2, 32, 32, 64, 64), (3, 4, 4, 128, 64)])
+def test_dgrad_epilogue_bn_backward_sums(B, H, W, cin, cout):
+    """conv_igemm_bnbwd: same gradient as the plain dgrad, and its per-tile partials fold to the same
+    (sum g', sum g'*xhat) / dgamma / dbeta / gx as the two-pass bn_bwd on that gradient."""
+    _, gp = _rand_act(B, H, W, cout, seed=51)                 # dL/d(conv output)
+    xf, xp = _rand_act(B, H, W, cin, seed=52, scale=1.5)      # BatchNorm input (the conv's pre-BN input)
+    _, w_int = _rand_weight(cout, cin, 3, seed=53)
+    wd = torch.empty(cin, 9, cout, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w_int.to(DEV), cout, 9, cin, None, wd)
+    g = torch.Generator().manual_seed(54)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.randn(cin, generator=g) * 0.3).to(DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * cin, device=DEV)
+    mean, rstd = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    ops.bn_stats(xp, scratch, mean, rstd)
+    (d,) = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 1)
+    ga_a, ga_b = ops.padded(B, H, W, cin, DEV), ops.padded(B, H, W, cin, DEV)
+    partials = torch.full((((B * H * W + 255) // 256) * 2 * cin,), float("nan"), device=DEV)
+    ops.conv_igemm(d, gp, wd, ga_a)
+    ops.conv_igemm_bnbwd(d, gp, wd, ga_b, xp, mean, rstd, gamma, beta, partials)
+    assert torch.equal(ga_a, ga_b)
+    dsum_r, dsum_f = torch.empty(2 * cin, device=DEV), torch.empty(2 * cin, device=DEV)
+    dg_r, db_r, dg_f, db_f = (torch.zeros(cin, device=DEV) for _ in range(4))
+    gx_r, gx_f = ops.padded(B, H, W, cin, DEV), ops.padded(B, H, W, cin, DEV)
+    ops.bn_bwd(ga_a, None, xp, mean, rstd, gamma, scratch, dsum_r, dg_r, db_r, gx_r, relu=True, beta=beta)
+    ops.bn_bwd_fused(ga_b, xp, mean, rstd, gamma, beta, partials, dsum_f, dg_f, db_f, gx_f)
+    scale = dsum_r.abs().max().item()
+    np.testing.assert_allclose(dsum_f.cpu().numpy(), dsum_r.cpu().numpy(), rtol=1e-3, atol=1e-4 * scale)
+    np.testing.assert_allclose(dg_f.cpu().numpy(), dg_r.cpu().numpy(), rtol=1e-3, atol=1e-4 * scale)
+    np.testing.assert_allclose(db_f.cpu().numpy(), db_r.cpu().numpy(), rtol=1e-3, atol=1e-4 * scale)
+    assert (gx_f.float() - gx_r.float()).abs().max().item() <= 2e-2 * gx_r.float().abs().max().item()
+
+
 def test_conv_identity_weights_are_transpose_detecting():
     # w[co][center][ci] = 1 if co == perm(ci): output channel co must equal input channel perm^-1(co)
     B, H, W, C = 2, 8, 8, 160

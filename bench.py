@@ -34,6 +34,23 @@ PEAK_BF16_TFLOPS = 2500.0
 GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_final_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of
+    this same command; scratch/prof_bench.sh).  bench.py cannot collect PMC counters itself -> null if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    n = b = 0
+    for name, v in t.items():
+        if "conv3x3_halo_kernel" in name or "conv_igemm_dma_kernel" in name:
+            n += v["launches"]
+            b += v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"])
+    return round(b / n) if n else None
+
+
 def cpu_baseline(batch, num_classes):
     """fp32 CPU oracle port timed on this box's host cores: one warm-up step at batch 8, one timed
     step at `batch` images (bounded sample of the same workload)."""
@@ -141,9 +158,11 @@ def main():
         summ = timer.summary()
         k = summ.get("conv_igemm")
         if k:
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + dgrad implicit GEMM)",
+            out["roofline"] = {"bound": "mfma",
+                               "kernel": "conv_igemm: conv3x3_halo_kernel / conv_igemm_dma_kernel (forward + "
+                                         "data-gradient implicit GEMM, 2/3 of the step's flops)",
                                "achieved": round(k["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
                                "avg_launch_us": round(k["avg_us"], 1),
                                "launches_per_step": k["launches"] // args.steps,
                                "flops_per_launch_avg": k["flops"] / k["launches"]}

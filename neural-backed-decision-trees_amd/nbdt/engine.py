@@ -247,13 +247,14 @@ class _Engine:
         # transpose kernel (one launch per optimizer step instead of one per layer)
         total = sum(c.numel() for c in self.convs)
         self._wd_flat = torch.empty(total, dtype=torch.bfloat16, device=self.device)
-        rows, off = [], 0
+        rows, off, tiles = [], 0, 0
         for c in self.convs:
-            rows.append([self.store.entries[c.name][0], off, c.cout, c.taps, c.cin, off])
+            rows.append([self.store.entries[c.name][0], off, c.cout, c.taps, c.cin, tiles])
             c.wd = self._wd_flat[off:off + c.numel()].view(c.cin, c.taps, c.cout)
             off += c.numel()
+            tiles += c.taps * (c.cout // 32) * (c.cin // 32)
         self._wd_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
-        self._wd_total = total
+        self._wd_total = tiles
         self.refresh_derived_weights()
 
     def refresh_derived_weights(self):

@@ -81,6 +81,19 @@ int nbdt_soft_backward(const nbdt_tree* t, const void* z, int ztype, int64_t B, 
 int nbdt_soft_tree_loss(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
                         const int64_t* y, float w_xent, float w_tree, float grad_scale,
                         float* row_loss, float* loss, float* gz, void* stream);
+/* HardTreeSupLoss.forward + backward fused (nbdt/loss.py:191-203, 212-257; label filtering
+ * nbdt/model.py:127-143) for criterion = nn.CrossEntropyLoss():
+ *   loss = mean_b[ w_xent*CE(z_b,y_b) + w_node * sum_{inner nodes n with y_b under n}
+ *                                                   CE(node_logits(z_b, n), child_of(n, y_b)) ]
+ * the caller folds the reference's weights into w_node = tree_weight * tsw * 2 / N (every pooled
+ * (sample,node) row weighs tsw/(B*N/2), then TreeSupLoss.forward applies the schedule).
+ * gz = grad_scale * dloss/dz.  row_loss: [B] fp32 scratch; loss: 1 fp32. */
+int nbdt_hard_tree_loss(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                        const int64_t* y, float w_xent, float w_node, float grad_scale,
+                        float* row_loss, float* loss, float* gz, void* stream);
+/* VJP of get_node_logits over every inner node (nbdt/model.py:83-99): gs [B,R] fp32 gradient of
+ * the child logits (slot-major, as written by nbdt_node_outputs) -> gz [B,C] fp32. */
+int nbdt_node_logits_backward(const nbdt_tree* t, const float* gs, int64_t B, float* gz, void* stream);
 /* HardEmbeddedDecisionRules.forward_with_decisions (nbdt/model.py:145-199): pred[B] int64,
  * optional onehot[B,C] fp32 (predicted_to_logits), optional decision buffers
  * [B, max_depth]: inode index / chosen child / its prob / node entropy (-1 padded). */

@@ -6,6 +6,7 @@
 //   Soft traverse_tree ..... nbdt/model.py:207-242   (class_probs[:, old] *= probs[:, new])
 //   Hard traverse_tree ..... nbdt/model.py:145-192   (per-sample python walk, D2H per node)
 //   SoftTreeSupLoss ........ nbdt/loss.py:191-203, 260-266  (+ autograd backward)
+//   HardTreeSupLoss ........ nbdt/loss.py:212-257, model.py:127-143 (+ autograd backward)
 // by ONE launch per call: a group of TPS lanes owns one sample; the sample's logits, the R child
 // logits and the R child probabilities live in LDS; the hierarchy is a pair of CSR maps
 // (slot -> classes, class -> slots) read through L2.  HBM traffic is the algorithmic minimum
@@ -281,6 +282,97 @@ __global__ __launch_bounds__(kBlock) void soft_loss_kernel(TreeView t, const voi
   tree_backward<TPS>(t, active, g_tid, ss, ps, pq);
   if (active)
     for (int c = g_tid; c < t.C; c += TPS) gz[sample * t.C + c] = gx[c] + class_grad(t, c, ss);
+}
+
+// HardTreeSupLoss forward+backward for criterion = nn.CrossEntropyLoss() (nbdt/loss.py:212-257):
+//   row = w_x*(lse(z) - z[y]) + w_h * sum over inner nodes n with y under n of
+//                                     (lse(s[n,:]) - s[n, child_of(n,y)])
+//   (w_h folds the reference's pooled-by-child-count means: every (sample,node) term ends up with
+//    the same weight tsw/(B*N/2), loss.py:228,250-256, times the scheduled tree weight, :195-203)
+// The nodes on the label's path are exactly the class->slot CSR row of y; a class listed under two
+// children of one node counts once, for the first child (model.py:135 `cls[0]`).
+template <int TPS, typename LD>
+__global__ __launch_bounds__(kBlock) void hard_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+                                                           const int64_t* __restrict__ y, float w_x,
+                                                           float w_h, float scale,
+                                                           float* __restrict__ row_loss,
+                                                           float* __restrict__ gz) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SPB = kBlock / TPS;
+  const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
+  const int64_t sample = (int64_t)blockIdx.x * SPB + g;
+  const bool active = sample < B;
+  const int stride = 2 * t.C + 2 * t.R + 8;
+  float* zs = lds + (size_t)g * stride;
+  float* ss = zs + t.C;
+  float* ds = ss + t.R;
+  float* gx = ds + t.R;
+  float* red = gx + t.C;
+  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
+  if (active)
+    for (int s = g_tid; s < t.R; s += TPS) ds[s] = 0.f;
+  __syncthreads();
+
+  int64_t yy = 0;
+  bool valid = false;
+  if (active) {
+    yy = y[sample];
+    valid = yy >= 0 && yy < t.C;
+  }
+  float tree_rows = 0.f;
+  if (valid) {
+    const int pb = t.cls_off[yy], pe = t.cls_off[yy + 1];
+    for (int j = pb + g_tid; j < pe; j += TPS) {
+      const int s = t.cls_slot[j];
+      // node owning slot s: last n with node_off[n] <= s
+      int lo = 0, hi = t.N - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.node_off[mid] <= s) lo = mid; else hi = mid - 1;
+      }
+      const int b = t.node_off[lo], e = t.node_off[lo + 1];
+      if (j > pb && t.cls_slot[j - 1] >= b) continue;  // same node, later child: not the first
+      float m = ss[b];
+      for (int q = b + 1; q < e; ++q) m = fmaxf(m, ss[q]);
+      float sum = 0.f;
+      for (int q = b; q < e; ++q) sum = sum + expf(ss[q] - m);
+      tree_rows += (logf(sum) + m) - ss[s];
+      for (int q = b; q < e; ++q)
+        ds[q] = (expf(ss[q] - m) / sum - (q == s ? 1.f : 0.f)) * (w_h * scale);
+    }
+  }
+  tree_rows = group_sum<TPS>(tree_rows, red, g_tid);
+
+  float mz = -INFINITY;
+  if (active)
+    for (int c = g_tid; c < t.C; c += TPS) mz = fmaxf(mz, zs[c]);
+  mz = group_max<TPS>(mz, red, g_tid);
+  float sz = 0.f;
+  if (active)
+    for (int c = g_tid; c < t.C; c += TPS) sz += expf(zs[c] - mz);
+  sz = group_sum<TPS>(sz, red, g_tid);
+  if (active) {
+    for (int c = g_tid; c < t.C; c += TPS) {
+      const float hot = (c == yy) ? 1.f : 0.f;
+      if (c == yy) row_loss[sample] = w_x * ((logf(sz) + mz) - zs[c]) + w_h * tree_rows;
+      gx[c] = (expf(zs[c] - mz) / sz - hot) * (w_x * scale);
+    }
+    if (!valid && g_tid == 0) row_loss[sample] = __uint_as_float(0x7fc00000u);  // loud: NaN loss
+  }
+  __syncthreads();
+  if (active)
+    for (int c = g_tid; c < t.C; c += TPS) gz[sample * t.C + c] = gx[c] + class_grad(t, c, ds);
+}
+
+// VJP of the node-logit map (nbdt/model.py:94-99): gz[b,c] = sum over slots s holding c of
+// gs[b,s] / |leaves(s)|.  Lets any torch criterion be composed on top of nbdt_node_outputs logits.
+__global__ __launch_bounds__(kBlock) void node_logits_bwd_kernel(TreeView t, const float* __restrict__ gs,
+                                                                 int64_t B, float* __restrict__ gz) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B * t.C) return;
+  const int64_t b = i / t.C;
+  const int c = (int)(i - b * t.C);
+  gz[i] = class_grad(t, c, gs + b * t.R);
 }
 
 __global__ __launch_bounds__(kBlock) void mean_kernel(const float* __restrict__ rows, int64_t n,
@@ -561,6 +653,36 @@ extern "C" int nbdt_soft_tree_loss(const nbdt_tree* t, const void* z, int ztype,
   NBDT_DISPATCH_RULES(soft_loss_kernel, 3 * t->C + 2 * t->R + 8, v, z, B, ldz, y, w_xent, w_tree, scale,
                       row_loss, gz);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, row_loss, B, loss);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_hard_tree_loss(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
+                                   const int64_t* y, float w_xent, float w_node, float grad_scale,
+                                   float* row_loss, float* loss, float* gz, void* stream) {
+  int rc = check_common(t, z, ztype, B, ldz);
+  if (rc) return rc;
+  NBDT_REQUIRE(y && row_loss && loss && gz, "null buffer");
+  NBDT_REQUIRE(B > 0, "empty batch has no mean loss");
+  TreeView v = view_of(t);
+  const float scale = grad_scale / (float)B;
+  NBDT_DISPATCH_RULES(hard_loss_kernel, 2 * t->C + 2 * t->R + 8, v, z, B, ldz, y, w_xent, w_node, scale,
+                      row_loss, gz);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, row_loss, B, loss);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_node_logits_backward(const nbdt_tree* t, const float* gs, int64_t B, float* gz,
+                                         void* stream) {
+  NBDT_REQUIRE(t != nullptr, "null tree handle");
+  NBDT_REQUIRE(B >= 0, "bad batch");
+  if (B == 0) return NBDT_OK;
+  NBDT_REQUIRE(gs && gz, "null gradient buffer");
+  TreeView v = view_of(t);
+  const int64_t n = B * t->C;
+  hipLaunchKernelGGL(node_logits_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, v, gs, B, gz);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

@@ -61,6 +61,9 @@ SIGNATURES = {
     "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,
                                     _P, _P, _P, _P]),
+    "nbdt_hard_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,
+                                    _P, _P, _P, _P]),
+    "nbdt_node_logits_backward": (c_int, [c_void_p, _P, c_int64, _P, _P]),
     "nbdt_hard_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nbdt_node_outputs": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
@@ -216,6 +219,38 @@ def soft_tree_loss(handle, z, y, w_xent, w_tree, grad_scale=1.0):
                                     float(w_tree), float(grad_scale), ptr(row), ptr(loss), ptr(gz),
                                     stream_of(z)))
     return loss, gz
+
+
+def hard_tree_loss(handle, z, y, w_xent, w_node, grad_scale=1.0):
+    """HardTreeSupLoss fused: returns (loss scalar tensor, gz [B,C] fp32)."""
+    require_gpu(z, "hard_tree_loss")
+    z, B, ld = _rows(z)
+    y = y.to(device=z.device, dtype=torch.int64).contiguous()
+    row = torch.empty((B,), dtype=torch.float32, device=z.device)
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    gz = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
+    check(lib().nbdt_hard_tree_loss(handle.h, ptr(z), ztype_of(z), B, ld, ptr(y), float(w_xent),
+                                    float(w_node), float(grad_scale), ptr(row), ptr(loss), ptr(gz),
+                                    stream_of(z)))
+    return loss, gz
+
+
+def node_logits(handle, z):
+    """[B, R] fp32 child logits of every inner node (slot-major)."""
+    require_gpu(z, "node_logits")
+    z, B, ld = _rows(z)
+    logits = torch.empty((B, handle.flat.num_slots), dtype=torch.float32, device=z.device)
+    check(lib().nbdt_node_outputs(handle.h, ptr(z), ztype_of(z), B, ld, ptr(logits), None, None, None,
+                                  stream_of(z)))
+    return logits
+
+
+def node_logits_backward(handle, gs):
+    require_gpu(gs, "node_logits_backward")
+    gs = gs.contiguous().float()
+    gz = torch.empty((gs.shape[0], handle.flat.num_classes), dtype=torch.float32, device=gs.device)
+    check(lib().nbdt_node_logits_backward(handle.h, ptr(gs), gs.shape[0], ptr(gz), stream_of(gs)))
+    return gz
 
 
 def hard_forward(handle, z, want_onehot=True, want_decisions=False):

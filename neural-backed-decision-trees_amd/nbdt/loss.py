@@ -10,7 +10,8 @@ When the wrapped criterion is a default ``nn.CrossEntropyLoss()`` the whole loss
 (csrc/rules.hip: soft_loss_kernel).  Any other criterion composes the fused rules kernel
 (autograd-enabled) with the user's criterion, exactly like the reference.
 
-``HardTreeSupLoss`` and ``SoftTreeLoss`` are "next" rows and raise.
+``HardTreeSupLoss`` (reference :212-257) gets the same treatment (hard_loss_kernel).  ``SoftTreeLoss``
+(mid-training hierarchy re-induction) raises.
 """
 import torch
 import torch.nn as nn
@@ -152,11 +153,83 @@ class SoftTreeSupLoss(TreeSupLoss):
                                  grad_scale)
 
 
+class _FusedHardTreeLossFn(torch.autograd.Function):
+    """HardTreeSupLoss and dloss/dz from one launch (csrc/rules.hip: hard_loss_kernel)."""
+
+    @staticmethod
+    def forward(ctx, z, y, tree, w_xent, w_node):
+        handle = tree.device_handle(z.device.index)
+        loss, gz = _C.hard_tree_loss(handle, z, y, w_xent, w_node)
+        ctx.save_for_backward(gz)
+        ctx.z_dtype = z.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (gz,) = ctx.saved_tensors
+        return (gz * gloss).to(ctx.z_dtype), None, None, None, None
+
+
 class HardTreeSupLoss(TreeSupLoss):
-    """reference nbdt/loss.py:212-257 -- scheduled after the soft path."""
+    """reference nbdt/loss.py:212-257: cross entropy at every inner node on the label's path.
+
+    With a default ``nn.CrossEntropyLoss()`` the whole loss and its gradient are one fused kernel.
+    Any other criterion follows the reference's structure -- rows pooled by the node's child count,
+    one criterion call per pool, weighted ``len(pool)/(B*N/2) * tree_supervision_weight`` -- on top
+    of ONE node-logit launch (differentiable) instead of a launch cascade per node.  Like the
+    reference, ``tree_supervision_weight`` ends up applied twice (inside ``forward_tree`` and
+    again by ``TreeSupLoss.forward``).
+    """
+
+    def _node_weight(self, tree_weight):
+        return float(tree_weight) * float(self.tree_supervision_weight) * 2.0 / len(self.tree.inodes)
 
     def forward_tree(self, outputs, targets):
-        raise NotImplementedError("HardTreeSupLoss is not built yet (SURVEY.md section 8f, rank 1)")
+        from nbdt.model import _NodeLogitsFn
+        self.assert_output_not_nbdt(outputs)
+        _C.require_gpu(outputs, "HardTreeSupLoss")
+        num_losses = outputs.size(0) * len(self.tree.inodes) / 2.0
+        logits = _NodeLogitsFn.apply(outputs, self.tree)            # [B, R], every node at once
+        node_off = self.tree.flat.node_off
+        targets_ints = [int(t) for t in targets.cpu().long()]
+        pools = {}                                                   # K -> (rows, first slot, target)
+        for n, node in enumerate(self.tree.inodes):
+            rows, base, tgt = pools.setdefault(node.num_classes, ([], [], []))
+            for b, t in enumerate(targets_ints):
+                child = node.class_index_to_child_index.get(t)
+                if child:
+                    rows.append(b)
+                    base.append(int(node_off[n]))
+                    tgt.append(child[0])
+        loss = 0
+        dev = outputs.device
+        for K, (rows, base, tgt) in pools.items():
+            if not rows:
+                continue
+            rows_t = torch.tensor(rows, device=dev).unsqueeze(1)
+            cols_t = torch.tensor(base, device=dev).unsqueeze(1) + torch.arange(K, device=dev)
+            outputs_sub = logits[rows_t, cols_t]
+            targets_sub = torch.tensor(tgt, device=dev, dtype=torch.long)
+            fraction = outputs_sub.size(0) / float(num_losses) * self.tree_supervision_weight
+            loss = loss + self.criterion(outputs_sub, targets_sub) * fraction
+        return loss
+
+    def forward(self, outputs, targets):
+        if _is_plain_cross_entropy(self.criterion) and outputs.dim() == 2:
+            self.assert_output_not_nbdt(outputs)
+            _C.require_gpu(outputs, "HardTreeSupLoss")
+            xent_weight, tree_weight = self.current_weights()
+            return _FusedHardTreeLossFn.apply(outputs, targets, self.tree, float(xent_weight),
+                                              self._node_weight(tree_weight))
+        return super().forward(outputs, targets)
+
+    def loss_and_grad(self, outputs, targets, grad_scale=1.0):
+        """Engine fast path: (loss, dloss/dz * grad_scale) from one launch, no autograd."""
+        self.assert_output_not_nbdt(outputs)
+        xent_weight, tree_weight = self.current_weights()
+        handle = self.tree.device_handle(outputs.device.index)
+        return _C.hard_tree_loss(handle, outputs, targets, float(xent_weight),
+                                 self._node_weight(tree_weight), grad_scale)
 
 
 class SoftTreeLoss(SoftTreeSupLoss):

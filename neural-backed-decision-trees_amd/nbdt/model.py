@@ -37,6 +37,21 @@ class _SoftRulesFn(torch.autograd.Function):
         return gz.to(z.dtype), None
 
 
+class _NodeLogitsFn(torch.autograd.Function):
+    """[B,R] child logits of every inner node; the VJP is one scatter-free gather kernel."""
+
+    @staticmethod
+    def forward(ctx, z, tree):
+        handle = tree.device_handle(z.device.index)
+        ctx.tree, ctx.z_dtype, ctx.dev = tree, z.dtype, z.device.index
+        return _C.node_logits(handle, z)
+
+    @staticmethod
+    def backward(ctx, gs):
+        handle = ctx.tree.device_handle(ctx.dev)
+        return _C.node_logits_backward(handle, gs).to(ctx.z_dtype), None
+
+
 class EmbeddedDecisionRules(nn.Module):
     """reference nbdt/model.py:65-123."""
 
@@ -64,10 +79,8 @@ class EmbeddedDecisionRules(nn.Module):
             raise NotImplementedError(
                 "get_node_logits without a node (ad-hoc class mapping) is not part of the HIP path")
         tree = node.tree
-        handle = tree.device_handle(outputs.device.index) if outputs.is_cuda else None
-        if handle is None:
-            _C.require_gpu(outputs, "get_node_logits")
-        logits, _, _, _ = _C.node_outputs(handle, outputs)
+        _C.require_gpu(outputs, "get_node_logits")
+        logits = _NodeLogitsFn.apply(outputs, tree)   # differentiable, like the reference's mean
         n = tree.flat.inode_wnids.index(node.wnid)
         b, e = int(tree.flat.node_off[n]), int(tree.flat.node_off[n + 1])
         return logits[:, b:e]
@@ -101,6 +114,19 @@ class EmbeddedDecisionRules(nn.Module):
 
 class HardEmbeddedDecisionRules(EmbeddedDecisionRules):
     """Greedy root->leaf traversal (reference :126-203); output is one-hot, detached."""
+
+    @classmethod
+    def get_node_logits_filtered(cls, node, outputs, targets):
+        """reference :127-143 -- rows whose label lies under `node`, their child logits and the
+        child index of each label (`class_index_to_child_index[t][0]`)."""
+        classes = [node.class_index_to_child_index[int(t)] for t in targets]
+        selector = [bool(c) for c in classes]
+        targets_sub = [c[0] for c in classes if c]
+        outputs = outputs[torch.tensor(selector, dtype=torch.bool, device=outputs.device)]
+        if outputs.size(0) == 0:
+            return selector, outputs[:, : node.num_classes], targets_sub
+        outputs_sub = cls.get_node_logits(outputs, node)
+        return selector, outputs_sub, targets_sub
 
     def predicted_to_logits(self, predicted):
         if self.I.device != predicted.device:

@@ -227,6 +227,63 @@ def soft_tree_sup_loss(tree, z, y, w_xent=1.0, w_tree=1.0):
     return F32(loss), dz.astype(F32)
 
 
+def hard_tree_sup_loss(tree, z, y, w_xent=1.0, tree_supervision_weight=1.0, w_tree=None):
+    """nbdt/loss.py:191-203 + 212-257 (HardTreeSupLoss) with criterion = CrossEntropyLoss.
+
+    For every inner node the samples whose label lies under the node form that node's
+    training set (model.py:127-143, get_node_logits_filtered: child index of the label =
+    ``class_index_to_child_index[y][0]``); rows are pooled by the node's number of children K and
+    each pool contributes ``CE_mean(pool) * len(pool) / (B*N/2) * tree_supervision_weight``
+    (loss.py:228, 250-256).  ``TreeSupLoss.forward`` then multiplies the sum by the scheduled
+    tree weight AGAIN (:195-203) -- ``w_tree`` here, which defaults to the attribute like the
+    reference's end==start schedule.  Returns (loss, dL/dz) with the closed-form gradient.
+    """
+    z = np.asarray(z, dtype=F32)
+    y = np.asarray(y, dtype=np.int64)
+    B, C = z.shape
+    w_tree = tree_supervision_weight if w_tree is None else w_tree
+    logits = node_logits(tree, z)
+    num_losses = B * tree.num_inodes / 2.0
+    rx, sx = _cross_entropy_rows(z, y)
+    onehot = np.zeros((B, C), dtype=F32)
+    onehot[np.arange(B), y] = 1
+    dz = ((sx - onehot) * F32(w_xent / B)).astype(F32)
+
+    pools = {}  # K -> (list of [rows,K] logits, list of targets, list of (node, rows))
+    for n, per_child in enumerate(tree.child_classes):
+        child_of = {}
+        for k, cls in enumerate(per_child):
+            for c in cls:
+                child_of.setdefault(c, k)          # cls[0]: first child holding the label
+        rows = np.array([b for b in range(B) if int(y[b]) in child_of], dtype=np.int64)
+        K = len(per_child)
+        pool = pools.setdefault(K, ([], [], []))
+        pool[0].append(logits[n][rows])
+        pool[1].extend(child_of[int(y[b])] for b in rows)
+        pool[2].append((n, rows))
+    loss_tree = F32(0)
+    for K, (subs, tgts, where) in pools.items():
+        sub = np.concatenate(subs, axis=0)
+        if not sub.shape[0]:
+            continue
+        tg = np.array(tgts, dtype=np.int64)
+        rows_ce, sm = _cross_entropy_rows(sub, tg)
+        fraction = sub.shape[0] / float(num_losses) * tree_supervision_weight
+        loss_tree = F32(loss_tree + rows_ce.mean(dtype=F32) * F32(fraction))
+        hot = np.zeros_like(sm)
+        hot[np.arange(sm.shape[0]), tg] = 1
+        ds_all = ((sm - hot) * F32(w_tree * tree_supervision_weight / num_losses)).astype(F32)
+        o = 0
+        for n, rows in where:
+            ds = ds_all[o:o + len(rows)]
+            o += len(rows)
+            for k, cls in enumerate(tree.child_classes[n]):
+                for c in cls:
+                    dz[rows, c] += (ds[:, k] / F32(len(cls))).astype(F32)
+    loss = F32(w_xent) * rx.mean(dtype=F32) + F32(w_tree) * loss_tree
+    return F32(loss), dz.astype(F32)
+
+
 def rules_backward(tree, z, gP, outs=None, P=None):
     """dL/dz of the soft rules layer for an upstream gradient gP = dL/dP."""
     z = np.asarray(z, dtype=F32)

@@ -19,6 +19,7 @@ Recorded per case (dataset, hierarchy, B, seed):
   hard_pred    HardEmbeddedDecisionRules preds (argmax of one-hot) nbdt/model.py:145-203
   loss, dz     SoftTreeSupLoss(CE)(z,y) and autograd dL/dz nbdt/loss.py:191-203,260-266
   loss_w, dz_w same with tree_supervision_weight=10, xent_weight=0.5
+  hloss, hdz   HardTreeSupLoss(CE)(z,y) and autograd dL/dz nbdt/loss.py:212-257 (+ _w variants)
   node_*       per-inode logits/probs/preds/entropy (forward_nodes) nbdt/model.py:101-123
   tree_*       the reference Tree's index maps (inode order, child->classes) nbdt/tree.py:105-125
 """
@@ -66,7 +67,7 @@ import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
 from nbdt.model import SoftEmbeddedDecisionRules, HardEmbeddedDecisionRules  # noqa: E402
-from nbdt.loss import SoftTreeSupLoss  # noqa: E402
+from nbdt.loss import SoftTreeSupLoss, HardTreeSupLoss  # noqa: E402
 from nbdt.tree import Tree  # noqa: E402
 
 torch.set_num_threads(8)
@@ -117,6 +118,13 @@ def run_case(tag, dataset, hierarchy, B, seed, scale):
         loss.backward()
         out["loss" + key] = np.float32(loss.item())
         out["dz" + key] = zz.grad.numpy()
+        # the other training loss: per-node cross entropy on the label's path (nbdt/loss.py:212-257)
+        crit = HardTreeSupLoss(dataset=dataset, criterion=nn.CrossEntropyLoss(), tree=tree, **kw)
+        zz = z.clone().requires_grad_(True)
+        loss = crit(zz, y)
+        loss.backward()
+        out["hloss" + key] = np.float32(loss.item())
+        out["hdz" + key] = zz.grad.numpy()
 
     # gradient of the bare rules layer under an arbitrary upstream gradient
     torch.manual_seed(seed + 100)

@@ -91,3 +91,16 @@ def test_weight_schedule():
     assert O.tree_weight(1.0, 1.0, 5.0) == 5.0
     assert O.tree_weight(0.0, 1.0, 5.0) == 1.0
     assert abs(O.tree_weight(0.5, 1.0, 5.0, power=2) - (0.75 * 1 + 0.25 * 5)) < 1e-12
+
+
+@pytest.mark.parametrize("tag", list(GOLDEN_CASES))
+def test_hard_loss_and_grad_match_reference(tag, golden_dir, pkg_dir):
+    """HardTreeSupLoss (nbdt/loss.py:212-257) incl. its tree_supervision_weight-applied-twice quirk."""
+    g, t = _load(tag, golden_dir, pkg_dir)
+    z, y = g["z"], g["y"]
+    loss, dz = O.hard_tree_sup_loss(t, z, y)
+    assert abs(loss - g["hloss"]) <= 1e-5 * abs(g["hloss"])
+    np.testing.assert_allclose(dz, g["hdz"], atol=1e-6, rtol=0)
+    loss_w, dz_w = O.hard_tree_sup_loss(t, z, y, w_xent=0.5, tree_supervision_weight=10.0)
+    assert abs(loss_w - g["hloss_w"]) <= 1e-5 * abs(g["hloss_w"])
+    np.testing.assert_allclose(dz_w, g["hdz_w"], atol=2e-6, rtol=1e-5)

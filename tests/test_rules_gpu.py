@@ -14,7 +14,7 @@ from conftest import GOLDEN_CASES
 pytestmark = pytest.mark.gpu
 
 from nbdt import _C  # noqa: E402
-from nbdt.loss import SoftTreeSupLoss  # noqa: E402
+from nbdt.loss import HardTreeSupLoss, SoftTreeSupLoss  # noqa: E402
 from nbdt.model import (HardEmbeddedDecisionRules, HardNBDT, SoftEmbeddedDecisionRules,  # noqa: E402
                         SoftNBDT)
 from nbdt.tree import Tree  # noqa: E402
@@ -66,6 +66,23 @@ def test_golden_inputs(tag, golden_dir, pkg_dir):
     gz = _C.soft_backward(handle, z, torch.from_numpy(g["gP"]).to(DEV)).cpu().numpy()
     np.testing.assert_allclose(gz, g["dz_rules"], atol=2e-6, rtol=1e-5)
 
+    # HardTreeSupLoss (nbdt/loss.py:212-257): fused kernel vs oracle vs the reference's autograd
+    N = len(tree.inodes)
+    for (wx, tsw, kl, kd) in [(1.0, 1.0, "hloss", "hdz"), (0.5, 10.0, "hloss_w", "hdz_w")]:
+        loss, gz = _C.hard_tree_loss(handle, z, y, wx, tsw * tsw * 2.0 / N)
+        lo, dzo = O.hard_tree_sup_loss(otree, g["z"], g["y"], wx, tsw)
+        assert abs(loss.item() - lo) <= 1e-5 * abs(lo)
+        assert abs(loss.item() - g[kl]) <= 1e-5 * abs(g[kl])
+        np.testing.assert_allclose(gz.cpu().numpy(), dzo, atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(gz.cpu().numpy(), g[kd], atol=2e-6, rtol=1e-5)
+        crit = HardTreeSupLoss(dataset=ds, criterion=nn.CrossEntropyLoss(), tree=tree,
+                               tree_supervision_weight=tsw, xent_weight=wx)
+        zz = z.clone().requires_grad_(True)
+        lm = crit(zz, y)
+        lm.backward()
+        assert abs(lm.item() - g[kl]) <= 1e-5 * abs(g[kl])
+        np.testing.assert_allclose(zz.grad.cpu().numpy(), g[kd], atol=2e-6, rtol=1e-5)
+
     logits, probs, preds, ent = (t.cpu().numpy() for t in _C.node_outputs(handle, z))
     assert np.array_equal(logits, np.concatenate([o["logits"] for o in outs], 1))  # same fp32 order
     np.testing.assert_allclose(probs, g["node_probs"], rtol=2e-5, atol=1e-6)
@@ -100,6 +117,11 @@ def test_full_size_vs_oracle(B, ds, h, pkg_dir):
     np.testing.assert_allclose(gz.cpu().numpy(), dzo, atol=1e-6, rtol=0)
     # gradient rows of a softmax-CE sum to ~0 (both terms): property check at full size
     assert np.abs(gz.cpu().numpy().sum(1)).max() < 1e-6
+    hl, hgz = _C.hard_tree_loss(handle, zd, yd, 1.0, 2.0 / len(tree.inodes))
+    hlo, hdzo = O.hard_tree_sup_loss(otree, z.numpy(), y.numpy())
+    assert abs(hl.item() - hlo) <= 1e-5 * abs(hlo)
+    np.testing.assert_allclose(hgz.cpu().numpy(), hdzo, atol=1e-6, rtol=1e-5)
+    assert np.abs(hgz.cpu().numpy().sum(1)).max() < 1e-6
 
 
 def test_edge_cases(pkg_dir):
@@ -195,6 +217,23 @@ def test_module_api_matches_reference_contracts(pkg_dir):
     np.testing.assert_allclose(z2.grad.cpu().numpy(), dzo, atol=2e-6, rtol=0)
     with pytest.raises(AssertionError):
         crit(P, y)
+    # HardTreeSupLoss: fused == composed (any criterion, pooled by child count like the reference)
+    hcrit = HardTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18",
+                            tree_supervision_weight=2.0)
+    hcrit2 = HardTreeSupLoss(dataset="CIFAR10", criterion=MyCE(), hierarchy="induced-ResNet18",
+                             tree_supervision_weight=2.0)
+    hlo, hdzo = O.hard_tree_sup_loss(otree, z.detach().cpu().numpy(), y.cpu().numpy(), 1.0, 2.0)
+    for c in (hcrit, hcrit2):
+        zh = z.detach().clone().requires_grad_(True)
+        lh = c(zh, y)
+        lh.backward()
+        assert abs(lh.item() - hlo) <= 1e-5 * abs(hlo)
+        np.testing.assert_allclose(zh.grad.cpu().numpy(), hdzo, atol=2e-6, rtol=1e-5)
+    with pytest.raises(AssertionError):
+        hcrit(P, y)
+    node = hcrit.tree.inodes[3]
+    sel, sub, tsub = HardEmbeddedDecisionRules.get_node_logits_filtered(node, z.detach(), y.tolist())
+    assert sub.shape == (sum(sel), node.num_classes) and len(tsub) == sum(sel)
     # epoch-dependent weights (nbdt/loss.py:187-189, 205-207)
     crit3 = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18",
                             tree_supervision_weight=1.0, tree_supervision_weight_end=5.0)

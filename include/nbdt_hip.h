@@ -219,13 +219,64 @@ int nbdt_pool_bn_bwd_apply(const float* gpooled, const void* x, const float* sav
                            const float* dsum, int32_t B, int32_t H, int32_t W, int32_t C, void* gx,
                            void* stream);
 
+/* ------------------------------------------------------------------ backbone: MBConv pieces (EfficientNet-B0)
+ * Replaces pytorchcv `efficientnet_b0` building blocks behind nbdt/models/__init__.py:3:
+ * dwconv{3x3,5x5}_block, BatchNorm2d + Swish, SEBlock, Dropout -- and their autograd.  Same padded NHWC
+ * bf16 tensors as above.  The activated tensor a = act(bn(x)) is never stored for the SE branch: every
+ * pass recomputes it from the raw conv output x and the saved batch statistics. */
+#define NBDT_ACT_NONE 0
+#define NBDT_ACT_RELU 1
+#define NBDT_ACT_SWISH 2
+/* y = act(bn(x)) [* gate[b][c]] [+ residual]        gate: fp32 [B][C] or NULL */
+int nbdt_bn_act_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                      const float* beta, int32_t act, const float* gate, const void* residual, int32_t B,
+                      int32_t H, int32_t W, int32_t C, void* y, void* stream);
+/* out[b][c] = scale * sum_hw act(bn(x)) [* mul]      (SE squeeze / head average pool with scale = 1/HW;
+ * with mul = upstream gradient and scale = 1: dL/dgate of the SE scaling).  out: fp32 [B][C], overwritten */
+int nbdt_bn_act_pool(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                     const float* beta, int32_t act, const void* mul, float scale, int32_t B, int32_t H,
+                     int32_t W, int32_t C, float* out, void* stream);
+/* backward of u = act(bn(x)) * gate (+ the pooled branch) w.r.t. x, gamma, beta in two passes:
+ *   gradient entering the activation g_a = gu                               (gate == NULL, gu != NULL)
+ *                                        = gu*gate[b][c] + gpool[b][c]/HW   (SE form)
+ *                                        = gpool[b][c]/HW                    (gu == NULL: average-pool head)
+ * dgamma/dbeta are accumulated (+=); gx [+= gx_add]; scratch/dsum as in nbdt_bn_bwd_reduce. */
+int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* gpool, const void* x,
+                    const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                    int32_t act, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
+                    float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx, void* stream);
+/* depthwise Conv2d(C, C, k in {3,5}, stride in {1,2}, padding k/2, groups=C): x [B][H+2][W+2][C] ->
+ * y [B][H/stride+2][W/stride+2][C]; w fp32 [k*k][C] (tap-major); dw accumulated (+=). */
+int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                    int32_t stride, void* y, void* stream);
+int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t k, int32_t stride, void* gx, void* stream);
+int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, int32_t H, int32_t W, int32_t C,
+                           int32_t k, int32_t stride, float* dw, void* stream);
+/* SEBlock gate: gate[b][c] = sigmoid(W2 swish(W1 pooled[b] + b1) + b2) for c < C_real, 0 above.
+ * pooled/gate rows have stride C; W1 [S][C_real], W2 [C_real][S]; pre1 [B][S] saved for backward. */
+int nbdt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int32_t B, int32_t C, int32_t C_real, int32_t S, float* pre1,
+                     float* gate, void* stream);
+/* dgate [B][C] -> gpool [B][C] (gradient of the pooled mean) and += dW1, db1, dW2, db2;
+ * dpre2 [B][C_real], dpre1 [B][S]: workspaces */
+int nbdt_se_gate_bwd(const float* dgate, const float* gate, const float* pre1, const float* pooled,
+                     const float* w1, const float* w2, int32_t B, int32_t C, int32_t C_real, int32_t S,
+                     float* dpre2, float* dpre1, float* gpool, float* dw1, float* db1, float* dw2,
+                     float* db2, void* stream);
+/* nn.Dropout(p) on n fp32 values: mask[i] in {0,1} from a counter hash of (seed, i); y = x*mask/(1-p) */
+int nbdt_dropout_fwd(const float* x, int64_t n, float p, uint32_t seed, uint8_t* mask, float* y,
+                     void* stream);
+int nbdt_dropout_bwd(const float* gy, int64_t n, float p, const uint8_t* mask, float* gx, void* stream);
+
 /* ------------------------------------------------------------------ stem / head / optimizer */
-/* stem Conv2d(3->cout_real, 3x3, pad 1) on NCHW fp32 images -> padded NHWC bf16 with `cpad`
- * channels (channels >= cout_real are zero).  w: fp32 [cout_real][3][3][3] (co, r, s, ci). */
+/* stem Conv2d(3->cout_real, 3x3, pad 1, stride 1|2) on NCHW fp32 images [B,3,H,W] -> padded NHWC
+ * bf16 [B][H/stride+2][W/stride+2][cpad] (channels >= cout_real are zero).
+ * w: fp32 [cout_real][3][3][3] (co, r, s, ci). */
 int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32_t W,
-                   int32_t cout_real, int32_t cpad, void* out, void* stream);
+                   int32_t cout_real, int32_t cpad, int32_t stride, void* out, void* stream);
 int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int32_t H, int32_t W,
-                    int32_t cout_real, int32_t cpad, float* dw, void* stream);
+                    int32_t cout_real, int32_t cpad, int32_t stride, float* dw, void* stream);
 /* nn.Linear: z[B][N] = x[B][K] w[N][K]^T + b (fp32) and its backward */
 int nbdt_linear_fwd(const float* x, const float* w, const float* b, int32_t B, int32_t K, int32_t N,
                     float* z, void* stream);

@@ -1,0 +1,748 @@
+// MBConv building blocks of EfficientNet-B0 on gfx950 (pytorchcv `efficientnet_b0`
+// behind reference nbdt/models/__init__.py:3): depthwise 3x3/5x5 convolution, BatchNorm + swish,
+// squeeze-and-excitation, dropout.  The 1x1 expand/project convolutions are the implicit-GEMM kernels
+// of conv_dma.hip; everything here is an HBM-bound streaming pass over padded NHWC bf16 tensors
+// (16-byte / 8-channel vectors per lane, a thread keeps ONE channel chunk and walks the pixels of ONE
+// image, so per-channel BatchNorm parameters and the per-(image, channel) SE gate live in registers).
+//
+// Nothing is materialised that can be recomputed from the raw conv output x in the same pass:
+//   a = swish(bn(x)) is never stored for the SE branch -- the pool pass reads x only, the scale pass
+//   writes a*gate directly, and every backward pass recomputes a / swish'(bn(x)) from x.
+// Algorithmic bytes per element: pool 2, apply/scale 4 (+2 residual), se_bwd_reduce 4,
+// bwd_reduce 4, bwd_apply 6 (+2 gx_add); depthwise fwd 4, bwd_data 4, bwd_weight 4.
+#include "common.h"
+
+using namespace nbdt;
+
+namespace {
+
+constexpr int kSlots = NBDT_BN_SLOTS;
+constexpr int kThreads = 256;
+
+struct MbGeom {
+  int B, H, W, C;
+  int hw, row, img;
+  FastDiv div_w;
+  int c8, PY, threads, slices;
+};
+
+MbGeom mb_geom(int B, int H, int W, int C, int ppt) {
+  MbGeom g;
+  g.B = B; g.H = H; g.W = W; g.C = C;
+  g.hw = H * W;
+  g.row = (W + 2) * C;
+  g.img = (H + 2) * g.row;
+  g.div_w = make_fastdiv((unsigned)W);
+  g.c8 = C / 8;
+  g.PY = kThreads / g.c8;
+  if (g.PY < 1) g.PY = 1;
+  if (g.PY > g.hw) g.PY = g.hw;
+  g.threads = g.c8 * g.PY;
+  g.slices = (g.hw + g.PY * ppt - 1) / (g.PY * ppt);
+  if (g.slices < 1) g.slices = 1;
+  return g;
+}
+
+int check_mb(int B, int H, int W, int C) {
+  NBDT_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "empty tensor");
+  NBDT_REQUIRE(C % 8 == 0 && C / 8 <= kThreads, "C must be a multiple of 8 and <= 2048");
+  NBDT_REQUIRE((long long)B * (H + 2) * (W + 2) * C < (1ll << 31), "tensor too large for 32-bit offsets");
+  return NBDT_OK;
+}
+
+__device__ __forceinline__ int pix_off(const MbGeom& g, int b, int p, int cx) {
+  const int h = (int)fdiv((unsigned)p, g.div_w);
+  const int w = p - h * g.W;
+  return b * g.img + (h + 1) * g.row + (w + 1) * g.C + cx * 8;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v) {
+  if (ACT == NBDT_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (ACT == NBDT_ACT_SWISH) return v * sigmoidf_(v);
+  return v;
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float v) {  // d act / d v
+  if (ACT == NBDT_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (ACT == NBDT_ACT_SWISH) {
+    const float s = sigmoidf_(v);
+    return s * (1.f + v * (1.f - s));
+  }
+  return 1.f;
+}
+
+struct BnRegs {
+  float sc[8], sh[8];
+};
+__device__ __forceinline__ void load_bn(BnRegs& r, const float* mean, const float* rstd, const float* gamma,
+                                        const float* beta, int cx) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    r.sc[i] = gamma[c] * rstd[c];
+    r.sh[i] = beta[c] - mean[c] * r.sc[i];
+  }
+}
+
+// fold NQ*8 per-thread partials over the PY pixel rows of the block; element e of chunk cx ends up in
+// thread (cx, e % PY) which hands it to `sink(q, channel, value)`
+template <int NQ, typename Sink>
+__device__ __forceinline__ void block_fold(float (&acc)[NQ][8], int cx, int py, int c8, int PY, float* lds,
+                                           Sink sink) {
+  float* mine = lds + ((size_t)py * c8 + cx) * (NQ * 8);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[q * 8 + i] = acc[q][i];
+  __syncthreads();
+  for (int e = py; e < NQ * 8; e += PY) {
+    float s = 0.f;
+    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + cx) * (NQ * 8) + e];
+    sink(e >> 3, cx * 8 + (e & 7), s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = act(bn(x)) [* gate[b,c]] [+ residual]
+template <int ACT, bool GATE, bool RES>
+__global__ __launch_bounds__(kThreads) void mb_apply_kernel(const bf16_t* __restrict__ x, const float* mean,
+                                                            const float* rstd, const float* gamma,
+                                                            const float* beta, const float* __restrict__ gate,
+                                                            const bf16_t* __restrict__ res, MbGeom g, int ppt,
+                                                            bf16_t* __restrict__ y) {
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  BnRegs bn;
+  load_bn(bn, mean, rstd, gamma, beta, cx);
+  float gt[8];
+  if (GATE)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gt[i] = gate[(size_t)b * g.C + cx * 8 + i];
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int k = 0; k < ppt; ++k) {
+    const int p = p0 + k * g.PY;
+    if (p >= g.hw) break;
+    const int o = pix_off(g, b, p, cx);
+    float f[8], r[8];
+    unpack8(*(const u32x4_t*)(x + o), f);
+    if (RES) unpack8(*(const u32x4_t*)(res + o), r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = act_fwd<ACT>(f[i] * bn.sc[i] + bn.sh[i]);
+      if (GATE) v *= gt[i];
+      if (RES) v += r[i];
+      f[i] = v;
+    }
+    *(u32x4_t*)(y + o) = pack8(f);
+  }
+}
+
+// out[b][c] += scale * sum_pixels  act(bn(x)) [* gu]      (SE squeeze; SE backward dL/dgate)
+template <int ACT, bool MUL>
+__global__ __launch_bounds__(kThreads) void mb_pool_kernel(const bf16_t* __restrict__ x, const float* mean,
+                                                           const float* rstd, const float* gamma,
+                                                           const float* beta, const bf16_t* __restrict__ gu,
+                                                           MbGeom g, int ppt, float scale,
+                                                           float* __restrict__ out) {
+  extern __shared__ float lds[];
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  BnRegs bn;
+  load_bn(bn, mean, rstd, gamma, beta, cx);
+  float acc[1][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int k = 0; k < ppt; ++k) {
+    const int p = p0 + k * g.PY;
+    if (p >= g.hw) break;
+    const int o = pix_off(g, b, p, cx);
+    float f[8], u[8];
+    unpack8(*(const u32x4_t*)(x + o), f);
+    if (MUL) unpack8(*(const u32x4_t*)(gu + o), u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = act_fwd<ACT>(f[i] * bn.sc[i] + bn.sh[i]);
+      if (MUL) v *= u[i];
+      acc[0][i] += v;
+    }
+  }
+  float* dst = out + (size_t)b * g.C;
+  block_fold<1>(acc, cx, py, g.c8, g.PY, lds, [&](int, int c, float s) { atomicAdd(dst + c, s * scale); });
+}
+
+// gradient entering the activation:  g_a = SE ? gu*gate[b,c] + gpool[b,c]/HW : (POOL ? gpooled[b,c]/HW : gu)
+// backward pass 1: per-channel sums of g_y = g_a * act'(y) and g_y * xhat  -> 32-slot scratch
+template <int ACT, bool SE, bool POOL>
+__global__ __launch_bounds__(kThreads) void mb_bwd_reduce_kernel(
+    const bf16_t* __restrict__ gu, const float* __restrict__ gate, const float* __restrict__ gpool,
+    const bf16_t* __restrict__ x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+    MbGeom g, int ppt, float* __restrict__ scratch) {
+  extern __shared__ float lds[];
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  BnRegs bn;
+  load_bn(bn, mean, rstd, gamma, beta, cx);
+  float mu[8], rs[8], gt[8], gp[8];
+  const float inv_hw = 1.f / (float)g.hw;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    if (SE) gt[i] = gate[(size_t)b * g.C + c];
+    if (SE || POOL) gp[i] = gpool[(size_t)b * g.C + c] * inv_hw;
+  }
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int k = 0; k < ppt; ++k) {
+    const int p = p0 + k * g.PY;
+    if (p >= g.hw) break;
+    const int o = pix_off(g, b, p, cx);
+    float fx[8], fg[8];
+    unpack8(*(const u32x4_t*)(x + o), fx);
+    if (!POOL) unpack8(*(const u32x4_t*)(gu + o), fg);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float ga = POOL ? gp[i] : fg[i];
+      if (SE) ga = ga * gt[i] + gp[i];
+      const float gy = ga * act_bwd<ACT>(fx[i] * bn.sc[i] + bn.sh[i]);
+      acc[0][i] += gy;
+      acc[1][i] += gy * ((fx[i] - mu[i]) * rs[i]);
+    }
+  }
+  const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kSlots - 1);
+  block_fold<2>(acc, cx, py, g.c8, g.PY, lds, [&](int q, int c, float s) {
+    atomicAdd(scratch + ((size_t)slot * 2 + q) * g.C + c, s);
+  });
+}
+
+// backward pass 2: gx = gamma*rstd * (g_y - mean(g_y) - xhat * mean(g_y*xhat)) [+ gx_add]
+template <int ACT, bool SE, bool POOL, bool HAS_ADD>
+__global__ __launch_bounds__(kThreads) void mb_bwd_apply_kernel(
+    const bf16_t* __restrict__ gu, const float* __restrict__ gate, const float* __restrict__ gpool,
+    const bf16_t* __restrict__ x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+    const float* __restrict__ dsum, const bf16_t* __restrict__ gx_add, MbGeom g, int ppt,
+    bf16_t* __restrict__ gx) {
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  BnRegs bn;
+  load_bn(bn, mean, rstd, gamma, beta, cx);
+  float mu[8], rs[8], gt[8], gp[8], k0[8], k1[8];
+  const float inv_hw = 1.f / (float)g.hw;
+  const float inv_n = 1.f / ((float)g.hw * (float)g.B);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    k0[i] = dsum[c] * inv_n;
+    k1[i] = dsum[g.C + c] * inv_n;
+    if (SE) gt[i] = gate[(size_t)b * g.C + c];
+    if (SE || POOL) gp[i] = gpool[(size_t)b * g.C + c] * inv_hw;
+  }
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int k = 0; k < ppt; ++k) {
+    const int p = p0 + k * g.PY;
+    if (p >= g.hw) break;
+    const int o = pix_off(g, b, p, cx);
+    float fx[8], fg[8], fa[8], out[8];
+    unpack8(*(const u32x4_t*)(x + o), fx);
+    if (!POOL) unpack8(*(const u32x4_t*)(gu + o), fg);
+    if (HAS_ADD) unpack8(*(const u32x4_t*)(gx_add + o), fa);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float ga = POOL ? gp[i] : fg[i];
+      if (SE) ga = ga * gt[i] + gp[i];
+      const float gy = ga * act_bwd<ACT>(fx[i] * bn.sc[i] + bn.sh[i]);
+      const float xh = (fx[i] - mu[i]) * rs[i];
+      float v = bn.sc[i] * (gy - k0[i] - xh * k1[i]);
+      if (HAS_ADD) v += fa[i];
+      out[i] = v;
+    }
+    *(u32x4_t*)(gx + o) = pack8(out);
+  }
+}
+
+__global__ __launch_bounds__(256) void mb_bwd_finalize_kernel(float* __restrict__ scratch, int C,
+                                                              float* __restrict__ dsum,
+                                                              float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < kSlots; ++k) {
+      s0 += scratch[((size_t)k * 2 + 0) * C + c];
+      s1 += scratch[((size_t)k * 2 + 1) * C + c];
+      scratch[((size_t)k * 2 + 0) * C + c] = 0.f;   // zero-on-entry contract for the next user
+      scratch[((size_t)k * 2 + 1) * C + c] = 0.f;
+    }
+    dsum[c] = s0;
+    dsum[C + c] = s1;
+    if (dbeta) dbeta[c] += s0;
+    if (dgamma) dgamma[c] += s1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise convolution, weights fp32 [k*k][C]; x padded [B][H+2][W+2][C], y padded [B][Ho+2][Wo+2][C]
+struct DwGeom {
+  MbGeom out;            // geometry of the OUTPUT tensor (Ho, Wo)
+  int Hi, Wi, rowi, imgi;
+  int k, stride, pad;
+};
+
+__global__ __launch_bounds__(kThreads) void dw_fwd_kernel(const bf16_t* __restrict__ x,
+                                                          const float* __restrict__ w, DwGeom d, int ppt,
+                                                          bf16_t* __restrict__ y) {
+  const MbGeom& g = d.out;
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int q = 0; q < ppt; ++q) {
+    const int p = p0 + q * g.PY;
+    if (p >= g.hw) break;
+    const int ho = (int)fdiv((unsigned)p, g.div_w);
+    const int wo = p - ho * g.W;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int r = 0; r < d.k; ++r) {
+      const int hi = ho * d.stride + r - d.pad;          // unpadded input row
+      if (hi < -1 || hi > d.Hi) continue;                // outside even the zero border
+      for (int s = 0; s < d.k; ++s) {
+        const int wi = wo * d.stride + s - d.pad;
+        if (wi < -1 || wi > d.Wi) continue;
+        float f[8];
+        unpack8(*(const u32x4_t*)(x + (size_t)b * d.imgi + (hi + 1) * d.rowi + (wi + 1) * g.C + cx * 8), f);
+        const float4 w0 = *(const float4*)(w + (size_t)(r * d.k + s) * g.C + cx * 8);
+        const float4 w1 = *(const float4*)(w + (size_t)(r * d.k + s) * g.C + cx * 8 + 4);
+        acc[0] += f[0] * w0.x; acc[1] += f[1] * w0.y; acc[2] += f[2] * w0.z; acc[3] += f[3] * w0.w;
+        acc[4] += f[4] * w1.x; acc[5] += f[5] * w1.y; acc[6] += f[6] * w1.z; acc[7] += f[7] * w1.w;
+      }
+    }
+    *(u32x4_t*)(y + pix_off(g, b, p, cx)) = pack8(acc);
+  }
+}
+
+// gx[hi][wi] = sum_{r,s : (hi+pad-r) % stride == 0, ...} gy[(hi+pad-r)/stride][(wi+pad-s)/stride] * w[r][s]
+// `in` = geometry of the INPUT-sized gradient being written
+__global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __restrict__ gy,
+                                                               const float* __restrict__ w, MbGeom in, int Ho,
+                                                               int Wo, int k, int stride, int pad, int ppt,
+                                                               bf16_t* __restrict__ gx) {
+  const int cx = threadIdx.x % in.c8, py = threadIdx.x / in.c8, b = blockIdx.y;
+  const int rowo = (Wo + 2) * in.C, imgo = (Ho + 2) * rowo;
+  const int p0 = blockIdx.x * in.PY * ppt + py;
+  for (int q = 0; q < ppt; ++q) {
+    const int p = p0 + q * in.PY;
+    if (p >= in.hw) break;
+    const int hi = (int)fdiv((unsigned)p, in.div_w);
+    const int wi = p - hi * in.W;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int r = 0; r < k; ++r) {
+      const int th = hi + pad - r;
+      if (th < 0 || (stride == 2 && (th & 1))) continue;
+      const int ho = stride == 2 ? th >> 1 : th;
+      if (ho >= Ho) continue;
+      for (int s = 0; s < k; ++s) {
+        const int tw = wi + pad - s;
+        if (tw < 0 || (stride == 2 && (tw & 1))) continue;
+        const int wo = stride == 2 ? tw >> 1 : tw;
+        if (wo >= Wo) continue;
+        float f[8];
+        unpack8(*(const u32x4_t*)(gy + (size_t)b * imgo + (ho + 1) * rowo + (wo + 1) * in.C + cx * 8), f);
+        const float4 w0 = *(const float4*)(w + (size_t)(r * k + s) * in.C + cx * 8);
+        const float4 w1 = *(const float4*)(w + (size_t)(r * k + s) * in.C + cx * 8 + 4);
+        acc[0] += f[0] * w0.x; acc[1] += f[1] * w0.y; acc[2] += f[2] * w0.z; acc[3] += f[3] * w0.w;
+        acc[4] += f[4] * w1.x; acc[5] += f[5] * w1.y; acc[6] += f[6] * w1.z; acc[7] += f[7] * w1.w;
+      }
+    }
+    *(u32x4_t*)(gx + pix_off(in, b, p, cx)) = pack8(acc);
+  }
+}
+
+// dw[r*k+s][c] += sum_{b, output pixels} gy * x[ho*stride + r - pad][wo*stride + s - pad]
+// blockIdx.z = kernel row r: K accumulators x 8 channels per thread
+template <int K>
+__global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* __restrict__ x,
+                                                                 const bf16_t* __restrict__ gy, DwGeom d, int ppt,
+                                                                 float* __restrict__ dw) {
+  extern __shared__ float lds[];
+  const MbGeom& g = d.out;
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y, r = blockIdx.z;
+  float acc[K][8];
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[s][i] = 0.f;
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int q = 0; q < ppt; ++q) {
+    const int p = p0 + q * g.PY;
+    if (p >= g.hw) break;
+    const int ho = (int)fdiv((unsigned)p, g.div_w);
+    const int wo = p - ho * g.W;
+    const int hi = ho * d.stride + r - d.pad;
+    if (hi < 0 || hi >= d.Hi) continue;
+    float fg[8];
+    unpack8(*(const u32x4_t*)(gy + pix_off(g, b, p, cx)), fg);
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      const int wi = wo * d.stride + s - d.pad;
+      if (wi < 0 || wi >= d.Wi) continue;
+      float f[8];
+      unpack8(*(const u32x4_t*)(x + (size_t)b * d.imgi + (hi + 1) * d.rowi + (wi + 1) * g.C + cx * 8), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[s][i] += fg[i] * f[i];
+    }
+  }
+  float* dst = dw + (size_t)r * K * g.C;
+  block_fold<K>(acc, cx, py, g.c8, g.PY, lds, [&](int s, int c, float v) { atomicAdd(dst + (size_t)s * g.C + c, v); });
+}
+
+// ------------------------------------------------------------------------------------------
+// squeeze-and-excitation gate.  One block per sample.
+//   hidden = swish(W1 pooled + b1)  [S];   gate = sigmoid(W2 hidden + b2)  [Cr];  gate[c >= Cr] = 0
+// W1 [S][Cr], W2 [Cr][S] (the 1x1 convs with bias of pytorchcv SEBlock), pooled/gate rows have stride C.
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled,
+                                                          const float* __restrict__ w1,
+                                                          const float* __restrict__ b1,
+                                                          const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, int C, int Cr, int S,
+                                                          float* __restrict__ pre1, float* __restrict__ gate) {
+  extern __shared__ float lds[];   // pooled[Cr] | h[S]
+  float* pl = lds;
+  float* hl = lds + Cr;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < Cr; c += 256) pl[c] = pooled[(size_t)b * C + c];
+  __syncthreads();
+  for (int s = wave; s < S; s += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < Cr; c += 64) acc += w1[(size_t)s * Cr + c] * pl[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float v = acc + b1[s];
+      pre1[(size_t)b * S + s] = v;
+      hl[s] = v * sigmoidf_(v);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = 0.f;
+    if (c < Cr) {
+      float acc = b2[c];
+      for (int s = 0; s < S; ++s) acc += w2[(size_t)c * S + s] * hl[s];
+      v = sigmoidf_(acc);
+    }
+    gate[(size_t)b * C + c] = v;
+  }
+}
+
+// per sample: dgate[b,c] (= sum_hw gu*a) -> dpre2[b,c], dpre1[b,s], gpool[b,c] (gradient of the pooled mean)
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate,
+                                                          const float* __restrict__ gate,
+                                                          const float* __restrict__ pre1,
+                                                          const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, int C, int Cr, int S,
+                                                          float* __restrict__ dpre2, float* __restrict__ dpre1,
+                                                          float* __restrict__ gpool) {
+  extern __shared__ float lds[];   // d2[Cr] | d1[S]
+  float* d2 = lds;
+  float* d1 = lds + Cr;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < Cr; c += 256) {
+    const float gt = gate[(size_t)b * C + c];
+    const float v = dgate[(size_t)b * C + c] * gt * (1.f - gt);
+    d2[c] = v;
+    dpre2[(size_t)b * Cr + c] = v;
+  }
+  __syncthreads();
+  for (int s = wave; s < S; s += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < Cr; c += 64) acc += w2[(size_t)c * S + s] * d2[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float p = pre1[(size_t)b * S + s];
+      const float sg = sigmoidf_(p);
+      const float v = acc * sg * (1.f + p * (1.f - sg));
+      d1[s] = v;
+      dpre1[(size_t)b * S + s] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    if (c < Cr)
+      for (int s = 0; s < S; ++s) acc += w1[(size_t)s * Cr + c] * d1[s];
+    gpool[(size_t)b * C + c] = acc;
+  }
+}
+
+// parameter gradients of the two SE projections, summed over the batch (thread per (c, s) pair)
+__global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restrict__ dpre2,
+                                                            const float* __restrict__ dpre1,
+                                                            const float* __restrict__ pre1,
+                                                            const float* __restrict__ pooled, int B, int C, int Cr,
+                                                            int S, float* __restrict__ dw1, float* __restrict__ db1,
+                                                            float* __restrict__ dw2, float* __restrict__ db2) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cr * S) return;
+  const int c = idx % Cr, s = idx / Cr;
+  float a1 = 0.f, a2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float p = pre1[(size_t)b * S + s];
+    const float h = p * sigmoidf_(p);
+    const float e1 = dpre1[(size_t)b * S + s], e2 = dpre2[(size_t)b * Cr + c];
+    a1 += e1 * pooled[(size_t)b * C + c];
+    a2 += e2 * h;
+    sb1 += e1;
+    sb2 += e2;
+  }
+  dw1[(size_t)s * Cr + c] += a1;
+  dw2[(size_t)c * S + s] += a2;
+  if (c == 0) db1[s] += sb1;
+  if (s == 0) db2[c] += sb2;
+}
+
+// ------------------------------------------------------------------------------------------
+// dropout on [n] fp32: keep-mask from a counter hash (seed, element index); y = x * mask / (1-p)
+__device__ __forceinline__ unsigned hash32(unsigned v) {
+  v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+  return v;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long long n, float p,
+                                                      float inv_keep, unsigned seed,
+                                                      unsigned char* __restrict__ mask, float* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned h = hash32((unsigned)i * 0x9e3779b9u + hash32(seed));
+  const bool keep = (float)(h >> 8) * (1.f / 16777216.f) >= p;
+  mask[i] = keep ? 1 : 0;
+  y[i] = keep ? x[i] * inv_keep : 0.f;
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ gy, long long n, float inv_keep,
+                                                          const unsigned char* __restrict__ mask,
+                                                          float* __restrict__ gx) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  gx[i] = mask[i] ? gy[i] * inv_keep : 0.f;
+}
+
+constexpr int kPpt = 8;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ host
+
+#define NBDT_ACT_SWITCH(act, MACRO)                                   \
+  do {                                                                \
+    if ((act) == NBDT_ACT_SWISH) { MACRO(NBDT_ACT_SWISH); }           \
+    else if ((act) == NBDT_ACT_RELU) { MACRO(NBDT_ACT_RELU); }        \
+    else { MACRO(NBDT_ACT_NONE); }                                    \
+  } while (0)
+
+extern "C" int nbdt_bn_act_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                 const float* beta, int32_t act, const float* gate, const void* residual, int32_t B,
+                                 int32_t H, int32_t W, int32_t C, void* y, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && y, "null argument");
+  NBDT_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  int rc = check_mb(B, H, W, C);
+  if (rc) return rc;
+  const MbGeom g = mb_geom(B, H, W, C, kPpt);
+  const dim3 grid(g.slices, B), blk(g.threads);
+  hipStream_t st = (hipStream_t)stream;
+#define NBDT_GO(A)                                                                                              \
+  do {                                                                                                          \
+    if (gate && residual) hipLaunchKernelGGL((mb_apply_kernel<A, true, true>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, gate, (const bf16_t*)residual, g, kPpt, (bf16_t*)y); \
+    else if (gate) hipLaunchKernelGGL((mb_apply_kernel<A, true, false>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, gate, (const bf16_t*)residual, g, kPpt, (bf16_t*)y); \
+    else if (residual) hipLaunchKernelGGL((mb_apply_kernel<A, false, true>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, gate, (const bf16_t*)residual, g, kPpt, (bf16_t*)y); \
+    else hipLaunchKernelGGL((mb_apply_kernel<A, false, false>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, gate, (const bf16_t*)residual, g, kPpt, (bf16_t*)y); \
+  } while (0)
+  NBDT_ACT_SWITCH(act, NBDT_GO);
+#undef NBDT_GO
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_act_pool(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                const float* beta, int32_t act, const void* mul, float scale, int32_t B, int32_t H,
+                                int32_t W, int32_t C, float* out, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && out, "null argument");
+  NBDT_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  int rc = check_mb(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  NBDT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), st));
+  const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
+  const dim3 grid(g.slices, B), blk(g.threads);
+  const size_t shmem = (size_t)g.threads * 8 * sizeof(float);
+#define NBDT_GO(A)                                                                                              \
+  do {                                                                                                          \
+    if (mul) hipLaunchKernelGGL((mb_pool_kernel<A, true>), grid, blk, shmem, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, (const bf16_t*)mul, g, 2 * kPpt, scale, out); \
+    else hipLaunchKernelGGL((mb_pool_kernel<A, false>), grid, blk, shmem, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, (const bf16_t*)mul, g, 2 * kPpt, scale, out); \
+  } while (0)
+  NBDT_ACT_SWITCH(act, NBDT_GO);
+#undef NBDT_GO
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* gpool, const void* x,
+                               const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                               int32_t act, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
+                               float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && scratch && dsum && gx, "null argument");
+  NBDT_REQUIRE(gu || (gpool && !gate), "need an upstream gradient tensor or a pooled gradient");
+  NBDT_REQUIRE(!gate || (gu && gpool), "the SE form needs gu, gate and gpool");
+  NBDT_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  int rc = check_mb(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const bool se = gate != nullptr, pool = gu == nullptr;
+  NBDT_REQUIRE(!(pool && gx_add), "pooled form has no gx_add");
+  {
+    const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
+    const dim3 grid(g.slices, B), blk(g.threads);
+    const size_t shmem = (size_t)g.threads * 16 * sizeof(float);
+#define NBDT_GO(A)                                                                                              \
+  do {                                                                                                          \
+    if (se) hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, true, false>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, scratch); \
+    else if (pool) hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, false, true>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, scratch); \
+    else hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, false, false>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, scratch); \
+  } while (0)
+    NBDT_ACT_SWITCH(act, NBDT_GO);
+#undef NBDT_GO
+    NBDT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(mb_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  {
+    const MbGeom g = mb_geom(B, H, W, C, kPpt);
+    const dim3 grid(g.slices, B), blk(g.threads);
+#define NBDT_GO(A)                                                                                              \
+  do {                                                                                                          \
+    if (se) { if (gx_add) hipLaunchKernelGGL((mb_bwd_apply_kernel<A, true, false, true>), grid, blk, 0, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, kPpt, (bf16_t*)gx); \
+              else hipLaunchKernelGGL((mb_bwd_apply_kernel<A, true, false, false>), grid, blk, 0, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, kPpt, (bf16_t*)gx); } \
+    else if (pool) hipLaunchKernelGGL((mb_bwd_apply_kernel<A, false, true, false>), grid, blk, 0, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, kPpt, (bf16_t*)gx); \
+    else { if (gx_add) hipLaunchKernelGGL((mb_bwd_apply_kernel<A, false, false, true>), grid, blk, 0, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, kPpt, (bf16_t*)gx); \
+           else hipLaunchKernelGGL((mb_bwd_apply_kernel<A, false, false, false>), grid, blk, 0, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, kPpt, (bf16_t*)gx); } \
+  } while (0)
+    NBDT_ACT_SWITCH(act, NBDT_GO);
+#undef NBDT_GO
+    NBDT_LAUNCH_CHECK();
+  }
+  return NBDT_OK;
+}
+
+static int check_dw(int B, int H, int W, int C, int k, int stride) {
+  int rc = check_mb(B, H, W, C);
+  if (rc) return rc;
+  NBDT_REQUIRE(k == 3 || k == 5, "depthwise kernel size must be 3 or 5");
+  NBDT_REQUIRE(stride == 1 || stride == 2, "stride must be 1 or 2");
+  NBDT_REQUIRE(H % stride == 0 && W % stride == 0, "spatial size must be divisible by the stride");
+  return NBDT_OK;
+}
+
+static DwGeom dw_geom(int B, int H, int W, int C, int k, int stride, int ppt) {
+  DwGeom d;
+  d.out = mb_geom(B, H / stride, W / stride, C, ppt);
+  d.Hi = H; d.Wi = W;
+  d.rowi = (W + 2) * C;
+  d.imgi = (H + 2) * d.rowi;
+  d.k = k; d.stride = stride; d.pad = k / 2;
+  return d;
+}
+
+extern "C" int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                               int32_t stride, void* y, void* stream) {
+  NBDT_REQUIRE(x && w && y, "null argument");
+  int rc = check_dw(B, H, W, C, k, stride);
+  if (rc) return rc;
+  const DwGeom d = dw_geom(B, H, W, C, k, stride, 4);
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(d.out.slices, B), dim3(d.out.threads), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, w, d, 4, (bf16_t*)y);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
+                                    int32_t k, int32_t stride, void* gx, void* stream) {
+  NBDT_REQUIRE(gy && w && gx, "null argument");
+  int rc = check_dw(B, H, W, C, k, stride);
+  if (rc) return rc;
+  const MbGeom in = mb_geom(B, H, W, C, 4);
+  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(in.slices, B), dim3(in.threads), 0, (hipStream_t)stream,
+                     (const bf16_t*)gy, w, in, H / stride, W / stride, k, stride, k / 2, 4, (bf16_t*)gx);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, int32_t H, int32_t W, int32_t C,
+                                      int32_t k, int32_t stride, float* dw, void* stream) {
+  NBDT_REQUIRE(x && gy && dw, "null argument");
+  int rc = check_dw(B, H, W, C, k, stride);
+  if (rc) return rc;
+  const int ppt = 32;
+  const DwGeom d = dw_geom(B, H, W, C, k, stride, ppt);
+  const dim3 grid(d.out.slices, B, k), blk(d.out.threads);
+  const size_t shmem = (size_t)d.out.threads * k * 8 * sizeof(float);
+  if (k == 3)
+    hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, grid, blk, shmem, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)gy, d, ppt, dw);
+  else
+    hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, grid, blk, shmem, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)gy, d, ppt, dw);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
+                                const float* b2, int32_t B, int32_t C, int32_t C_real, int32_t S, float* pre1,
+                                float* gate, void* stream) {
+  NBDT_REQUIRE(pooled && w1 && b1 && w2 && b2 && pre1 && gate, "null argument");
+  NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), (size_t)(C_real + S) * sizeof(float),
+                     (hipStream_t)stream, pooled, w1, b1, w2, b2, C, C_real, S, pre1, gate);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_se_gate_bwd(const float* dgate, const float* gate, const float* pre1, const float* pooled,
+                                const float* w1, const float* w2, int32_t B, int32_t C, int32_t C_real, int32_t S,
+                                float* dpre2, float* dpre1, float* gpool, float* dw1, float* db1, float* dw2,
+                                float* db2, void* stream) {
+  NBDT_REQUIRE(dgate && gate && pre1 && pooled && w1 && w2 && dpre2 && dpre1 && gpool && dw1 && db1 && dw2 && db2,
+               "null argument");
+  NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), (size_t)(C_real + S) * sizeof(float), st, dgate, gate,
+                     pre1, w1, w2, C, C_real, S, dpre2, dpre1, gpool);
+  NBDT_LAUNCH_CHECK();
+  const int n = C_real * S;
+  hipLaunchKernelGGL(se_param_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dpre2, dpre1, pre1, pooled, B, C,
+                     C_real, S, dw1, db1, dw2, db2);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_dropout_fwd(const float* x, int64_t n, float p, uint32_t seed, uint8_t* mask, float* y,
+                                void* stream) {
+  NBDT_REQUIRE(x && mask && y, "null argument");
+  NBDT_REQUIRE(n > 0 && p >= 0.f && p < 1.f, "bad dropout arguments");
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)n, p, 1.f / (1.f - p), seed, mask, y);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_dropout_bwd(const float* gy, int64_t n, float p, const uint8_t* mask, float* gx, void* stream) {
+  NBDT_REQUIRE(gy && mask && gx, "null argument");
+  NBDT_REQUIRE(n > 0 && p >= 0.f && p < 1.f, "bad dropout arguments");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                     (long long)n, 1.f / (1.f - p), mask, gx);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}

@@ -15,26 +15,27 @@ using namespace nbdt;
 // ------------------------------------------------------------------------------------------ stem
 // thread = (pixel, 8-cout chunk); weights [cout][3][3][3] (co, r, s, ci) staged in LDS
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w,
-                                                        int B, int H, int W, int cout, int cpad,
+                                                        int B, int H, int W, int cout, int cpad, int stride,
                                                         bf16_t* __restrict__ out) {
   extern __shared__ float wl[];  // [cout][27]
   for (int i = threadIdx.x; i < cout * 27; i += 256) wl[i] = w[i];
   __syncthreads();
   const int chunks = cout / 8;
-  const long long total = (long long)B * H * W * chunks;
+  const int Ho = H / stride, Wo = W / stride;   // H, W: image size; output is Ho x Wo
+  const long long total = (long long)B * Ho * Wo * chunks;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int ck = (int)(idx % chunks);
   const int p = (int)(idx / chunks);
-  const int x = p % W, y = (p / W) % H, b = p / (W * H);
+  const int x = p % Wo, y = (p / Wo) % Ho, b = p / (Wo * Ho);
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   for (int r = 0; r < 3; ++r) {
-    const int yy = y + r - 1;
+    const int yy = y * stride + r - 1;
     if (yy < 0 || yy >= H) continue;
     for (int s = 0; s < 3; ++s) {
-      const int xx = x + s - 1;
+      const int xx = x * stride + s - 1;
       if (xx < 0 || xx >= W) continue;
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci) {
@@ -44,18 +45,19 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       }
     }
   }
-  const size_t o = (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * cpad + ck * 8;
+  const size_t o = (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + ck * 8;
   *(u32x4_t*)(out + o) = pack8(acc);
 }
 
 // dw[co][27] += sum_pixels gy[pix][co] * img[tap]; block = pixel range, 64-pixel tiles in LDS
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gy,
-                                                         int B, int H, int W, int cout, int cpad, int tiles_per_block,
-                                                         float* __restrict__ dw) {
+                                                         int B, int H, int W, int cout, int cpad, int stride,
+                                                         int tiles_per_block, float* __restrict__ dw) {
   extern __shared__ float lds[];  // gy tile [64][cout] then patch tile [64][27]
   float* gl = lds;
   float* pl = lds + 64 * cout;
-  const int npix = B * H * W;
+  const int Ho = H / stride, Wo = W / stride;
+  const int npix = B * Ho * Wo;
   const int nout = cout * 27;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // outputs tid, tid+256, ... (<= 2048)
   for (int t = 0; t < tiles_per_block; ++t) {
@@ -66,8 +68,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       const int pp = p0 + i / cout, co = i % cout;
       float v = 0.f;
       if (pp < npix) {
-        const int x = pp % W, y = (pp / W) % H, b = pp / (W * H);
-        v = bf16_to_f32(gy[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * cpad + co]);
+        const int x = pp % Wo, y = (pp / Wo) % Ho, b = pp / (Wo * Ho);
+        v = bf16_to_f32(gy[(((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + co]);
       }
       gl[i] = v;
     }
@@ -75,9 +77,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       const int pp = p0 + i / 27, k = i % 27;
       float v = 0.f;
       if (pp < npix) {
-        const int x = pp % W, y = (pp / W) % H, b = pp / (W * H);
+        const int x = pp % Wo, y = (pp / Wo) % Ho, b = pp / (Wo * Ho);
         const int r = k / 9, s = (k / 3) % 3, ci = k % 3;
-        const int yy = y + r - 1, xx = x + s - 1;
+        const int yy = y * stride + r - 1, xx = x * stride + s - 1;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
       }
       pl[i] = v;
@@ -102,29 +104,31 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 }
 
 extern "C" int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32_t W, int32_t cout_real,
-                              int32_t cpad, void* out, void* stream) {
+                              int32_t cpad, int32_t stride, void* out, void* stream) {
   NBDT_REQUIRE(img && w && out, "null argument");
   NBDT_REQUIRE(B > 0 && H > 0 && W > 0, "empty image batch");
+  NBDT_REQUIRE((stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0, "bad stem stride");
   NBDT_REQUIRE(cout_real > 0 && cout_real % 8 == 0 && cout_real <= cpad && cpad % 8 == 0, "bad stem channels");
-  const long long total = (long long)B * H * W * (cout_real / 8);
+  const long long total = (long long)B * (H / stride) * (W / stride) * (cout_real / 8);
   hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), cout_real * 27 * sizeof(float),
-                     (hipStream_t)stream, img, w, B, H, W, cout_real, cpad, (bf16_t*)out);
+                     (hipStream_t)stream, img, w, B, H, W, cout_real, cpad, stride, (bf16_t*)out);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
 
 extern "C" int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int32_t H, int32_t W, int32_t cout_real,
-                               int32_t cpad, float* dw, void* stream) {
+                               int32_t cpad, int32_t stride, float* dw, void* stream) {
   NBDT_REQUIRE(img && gy && dw, "null argument");
+  NBDT_REQUIRE((stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0, "bad stem stride");
   NBDT_REQUIRE(cout_real > 0 && cout_real * 27 <= 2048 && cout_real <= cpad, "stem wgrad supports cout <= 75");
-  const int npix = B * H * W;
+  const int npix = B * (H / stride) * (W / stride);
   const int tiles = (npix + 63) / 64;
   int blocks = tiles < 1024 ? tiles : 1024;
   const int tpb = (tiles + blocks - 1) / blocks;
   blocks = (tiles + tpb - 1) / tpb;
   const size_t shmem = (size_t)(64 * cout_real + 64 * 27) * sizeof(float);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, img,
-                     (const bf16_t*)gy, B, H, W, cout_real, cpad, tpb, dw);
+                     (const bf16_t*)gy, B, H, W, cout_real, cpad, stride, tpb, dw);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

@@ -85,8 +85,21 @@ SIGNATURES = {
                                         _P, _P, _P]),
     "nbdt_pool_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
                                        _P]),
-    "nbdt_stem_conv": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    "nbdt_stem_wgrad": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_stem_conv": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_stem_wgrad": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_act_apply": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_act_pool": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_float, c_int32, c_int32, c_int32, c_int32,
+                                 _P, _P]),
+    "nbdt_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32,
+                                _P, _P, _P, _P, _P, _P]),
+    "nbdt_dwconv_fwd": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_dwconv_bwd_data": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_dwconv_bwd_weight": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_se_gate_fwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "nbdt_se_gate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P,
+                                 _P, _P, _P]),
+    "nbdt_dropout_fwd": (c_int, [_P, c_int64, c_float, ctypes.c_uint32, _P, _P, _P]),
+    "nbdt_dropout_bwd": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "nbdt_linear_fwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_linear_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
     "nbdt_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),

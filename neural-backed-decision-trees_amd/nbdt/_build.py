@@ -30,6 +30,7 @@ FLAGS = {
     "wgrad_taps.hip": ["-munsafe-fp-atomics"],
     "bn.hip": ["-munsafe-fp-atomics"],
     "misc.hip": ["-munsafe-fp-atomics"],
+    "effnet.hip": ["-munsafe-fp-atomics"],
 }
 
 

@@ -1,0 +1,323 @@
+"""EfficientNet-B0 execution engine (SURVEY.md row A4 / BASELINE config 5).
+
+Restates pytorchcv's ``efficientnet_b0`` (the model the reference re-exports at
+nbdt/models/__init__.py:3 and names in README.md:141-151) as a fixed launch sequence over the HIP
+kernels: 1x1 expand / project convolutions are the implicit-GEMM kernels (csrc/conv_dma.hip) with the
+following BatchNorm's statistics fused into their epilogue; depthwise convolutions, BatchNorm + swish,
+squeeze-and-excitation and dropout are the streaming kernels of csrc/effnet.hip.  State-dict names and
+logical shapes follow pytorchcv (``features.stageS.unitU.{conv1,conv2,se,conv3}``,
+``features.final_block``, ``output.fc``).
+
+Per MBConv unit the forward keeps only raw conv outputs + the tensors the next conv must read
+(e_raw, e_act, d_raw, d_se, p_raw, out); the swish / SE-scaled activations needed by the backward are
+recomputed from the raw outputs inside the backward kernels.
+"""
+import math
+
+import torch
+
+from nbdt import ops
+from nbdt.engine import _Engine, _pad32
+
+# (stage stride, [(out_channels, kernel, expansion), ...]) -- pytorchcv get_efficientnet(version="b0")
+B0_STAGES = [
+    (1, [(16, 3, 1)]),
+    (2, [(24, 3, 6), (24, 3, 6)]),
+    (2, [(40, 5, 6), (40, 5, 6)]),
+    (2, [(80, 3, 6)] * 3 + [(112, 5, 6)] * 3),
+    (2, [(192, 5, 6)] * 4 + [(320, 3, 6)]),
+]
+ACT = ops.ACT_SWISH
+
+
+class DepthwiseConv:
+    """groups=C Conv2d(k, stride, padding=k//2), bias-free; master weights fp32 [k*k][Cpad]."""
+
+    def __init__(self, store, name, c_real, k, stride, gen):
+        self.store, self.name, self.c_real, self.k, self.stride = store, name, c_real, k, stride
+        self.C = _pad32(c_real)
+        bound = math.sqrt(2.0) * math.sqrt(3.0 / (k * k))   # kaiming_uniform_(a=0), fan_in = k*k
+
+        def init(v):
+            v.zero_()
+            v[:, :c_real].uniform_(-bound, bound, generator=gen)
+
+        store.add(name, (k * k, self.C), init)
+
+    def logical(self, buf):
+        v = self.store._view(buf, self.name).view(self.k, self.k, self.C)
+        return v[:, :, :self.c_real].permute(2, 0, 1).unsqueeze(1)      # [C, 1, k, k]
+
+    def forward(self, x, y):
+        ops.dwconv_fwd(x, self.store.p(self.name), y, self.k, self.stride)
+
+    def backward_data(self, gy, gx):
+        ops.dwconv_bwd_data(gy, self.store.p(self.name), gx, self.k, self.stride)
+
+    def backward_weight(self, x, gy):
+        ops.dwconv_bwd_weight(x, gy, self.store.g(self.name), self.k, self.stride)
+
+
+class SqueezeExcite:
+    """pytorchcv SEBlock: two biased 1x1 convs on the pooled vector (swish, sigmoid)."""
+
+    def __init__(self, store, name, c_real, mid, gen):
+        self.store, self.name, self.c_real, self.mid = store, name, c_real, mid
+        b1 = math.sqrt(2.0) * math.sqrt(3.0 / c_real)
+        b2 = math.sqrt(2.0) * math.sqrt(3.0 / mid)
+        store.add(name + ".conv1.weight", (mid, c_real), lambda v: v.uniform_(-b1, b1, generator=gen))
+        store.add(name + ".conv1.bias", (mid,), lambda v: v.zero_())
+        store.add(name + ".conv2.weight", (c_real, mid), lambda v: v.uniform_(-b2, b2, generator=gen))
+        store.add(name + ".conv2.bias", (c_real,), lambda v: v.zero_())
+
+    def views(self, buf):
+        s, n = self.store, self.name
+        return {
+            n + ".conv1.weight": s._view(buf, n + ".conv1.weight").view(self.mid, self.c_real, 1, 1),
+            n + ".conv1.bias": s._view(buf, n + ".conv1.bias"),
+            n + ".conv2.weight": s._view(buf, n + ".conv2.weight").view(self.c_real, self.mid, 1, 1),
+            n + ".conv2.bias": s._view(buf, n + ".conv2.bias"),
+        }
+
+    def forward(self, pooled, pre1, gate):
+        p = self.store.p
+        ops.se_gate_fwd(pooled, p(self.name + ".conv1.weight"), p(self.name + ".conv1.bias"),
+                        p(self.name + ".conv2.weight"), p(self.name + ".conv2.bias"), pre1, gate, self.c_real)
+
+    def backward(self, dgate, gate, pre1, pooled, dpre2, dpre1, gpool):
+        p, g = self.store.p, self.store.g
+        ops.se_gate_bwd(dgate, gate, pre1, pooled, p(self.name + ".conv1.weight"), p(self.name + ".conv2.weight"),
+                        dpre2, dpre1, gpool, g(self.name + ".conv1.weight"), g(self.name + ".conv1.bias"),
+                        g(self.name + ".conv2.weight"), g(self.name + ".conv2.bias"), self.c_real)
+
+
+class EfficientNetEngine(_Engine):
+    def __init__(self, num_classes=1000, dropout_rate=0.2, stages=B0_STAGES, init_channels=32,
+                 final_channels=1280, device="cuda", seed=0):
+        super().__init__(device, seed)
+        self.num_classes, self.dropout_rate = num_classes, float(dropout_rate)
+        gen = self.gen
+        self.stem_c = init_channels
+        b0 = math.sqrt(2.0) * math.sqrt(3.0 / 27)
+        self.store.add("features.init_block.conv.conv.weight", (init_channels, 3, 3, 3),
+                       lambda v: v.uniform_(-b0, b0, generator=gen))
+        self.bn0 = self.bn("features.init_block.conv.bn", init_channels)
+        self.units, self.dws, self.ses = [], [], []
+        cin = init_channels
+        for i, (stage_stride, specs) in enumerate(stages):
+            for j, (cout, k, exp) in enumerate(specs):
+                stride = stage_stride if j == 0 else 1
+                pre = f"features.stage{i + 1}.unit{j + 1}."
+                mid = cin * exp
+                u = {"cin": cin, "cout": cout, "mid": mid, "k": k, "stride": stride, "exp": exp,
+                     "key": f"s{i + 1}u{j + 1}", "stage": i + 1, "residual": cin == cout and stride == 1}
+                if i == 0:   # EffiDwsConvUnit: depthwise -> SE -> pointwise
+                    u["conv1"] = u["bn1"] = None
+                    u["dw"] = DepthwiseConv(self.store, pre + "dw_conv.conv.weight", mid, k, stride, gen)
+                    u["bn2"] = self.bn(pre + "dw_conv.bn", mid)
+                    u["se"] = SqueezeExcite(self.store, pre + "se", mid, mid // 4, gen)
+                    u["conv3"] = self.conv(pre + "pw_conv.conv.weight", mid, cout, 1, 1)
+                    u["bn3"] = self.bn(pre + "pw_conv.bn", cout)
+                else:        # EffiInvResUnit: expand -> depthwise -> SE -> project
+                    u["conv1"] = self.conv(pre + "conv1.conv.weight", cin, mid, 1, 1)
+                    u["bn1"] = self.bn(pre + "conv1.bn", mid)
+                    u["dw"] = DepthwiseConv(self.store, pre + "conv2.conv.weight", mid, k, stride, gen)
+                    u["bn2"] = self.bn(pre + "conv2.bn", mid)
+                    u["se"] = SqueezeExcite(self.store, pre + "se", mid, mid // (exp * 4), gen)
+                    u["conv3"] = self.conv(pre + "conv3.conv.weight", mid, cout, 1, 1)
+                    u["bn3"] = self.bn(pre + "conv3.bn", cout)
+                self.dws.append(u["dw"])
+                self.ses.append(u["se"])
+                self.units.append(u)
+                cin = cout
+        self.final_conv = self.conv("features.final_block.conv.weight", cin, final_channels, 1, 1)
+        self.final_bn = self.bn("features.final_block.bn", final_channels)
+        self.feat_c = final_channels
+        kb = 1.0 / math.sqrt(final_channels)
+        self.store.add("output.fc.weight", (num_classes, final_channels), lambda v: v.uniform_(-kb, kb, generator=gen))
+        self.store.add("output.fc.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
+        self.finalize()
+        self._step = 0
+        self.dropout_seed = seed
+
+    # ------------------------------------------------------------------ reference-named views
+    def extra_param_views(self, buf):
+        out = {
+            "features.init_block.conv.conv.weight":
+                self.store._view(buf, "features.init_block.conv.conv.weight").permute(0, 3, 1, 2),
+            "output.fc.weight": self.store._view(buf, "output.fc.weight"),
+            "output.fc.bias": self.store._view(buf, "output.fc.bias"),
+        }
+        for d in self.dws:
+            out[d.name] = d.logical(buf)
+        for s in self.ses:
+            out.update(s.views(buf))
+        return out
+
+    def grad_buckets(self):
+        """Flat-gradient ranges in the order backward completes them: [stage5..classifier], [stage3..4],
+        [stem..stage2]."""
+        ent = self.store.entries
+        s3 = ent["features.stage3.unit1.conv1.conv.weight"][0]
+        s5 = ent["features.stage5.unit1.conv1.conv.weight"][0]
+        return [(s5, self.store.grad.numel()), (s3, s5), (0, s3)]
+
+    def _vec(self, key, B, n):
+        return self._tensor(key, (B, n))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img, training=None):
+        training = self.training if training is None else training
+        if img.dtype != torch.float32 or not img.is_contiguous():
+            img = img.float().contiguous()
+        B, _, H, W = img.shape
+        if H % 32 or W % 32:
+            raise ValueError("EfficientNet input size must be a multiple of 32")
+        self._img, self._B = img, B
+        fuse = training and self.fuse_stats
+        h, w = H // 2, W // 2
+        c0 = _pad32(self.stem_c)
+        t0 = self.buf("t0", B, h, w, c0)
+        x = self.buf("a0", B, h, w, c0)
+        ops.stem_conv(img, self.store.p("features.init_block.conv.conv.weight"), t0, self.stem_c, stride=2)
+        self.bn0.stats(t0, training)
+        bn = self.bn0
+        ops.bn_act_apply(t0, bn.mean, bn.rstd, bn.gamma, bn.beta, x, act=ACT)
+        for u in self.units:
+            k, s = u["key"], u["stride"]
+            cin, mid, cout = _pad32(u["cin"]), _pad32(u["mid"]), _pad32(u["cout"])
+            ho, wo = h // s, w // s
+            if u["conv1"] is not None:
+                e_raw = self.buf(k + ".e_raw", B, h, w, mid)
+                e_act = self.buf(k + ".e_act", B, h, w, mid)
+                u["conv1"].forward(x, e_raw, bn_scratch=self.partials(e_raw) if fuse else None)
+                bn = u["bn1"]
+                bn.stats(e_raw, training, fused=fuse)
+                ops.bn_act_apply(e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, e_act, act=ACT)
+            else:
+                e_act = x
+            d_raw = self.buf(k + ".d_raw", B, ho, wo, mid)
+            d_se = self.buf(k + ".d_se", B, ho, wo, mid)
+            u["dw"].forward(e_act, d_raw)
+            bn = u["bn2"]
+            bn.stats(d_raw, training)
+            pooled, gate = self._vec(k + ".pooled", B, mid), self._vec(k + ".gate", B, mid)
+            pre1 = self._vec(k + ".pre1", B, u["se"].mid)
+            ops.bn_act_pool(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, pooled, act=ACT)
+            u["se"].forward(pooled, pre1, gate)
+            ops.bn_act_apply(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, d_se, act=ACT, gate=gate)
+            p_raw = self.buf(k + ".p_raw", B, ho, wo, cout)
+            out = self.buf(k + ".out", B, ho, wo, cout)
+            u["conv3"].forward(d_se, p_raw, bn_scratch=self.partials(p_raw) if fuse else None)
+            bn = u["bn3"]
+            bn.stats(p_raw, training, fused=fuse)
+            ops.bn_act_apply(p_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, out, act=ops.ACT_NONE,
+                             residual=x if u["residual"] else None)
+            u["x_in"], u["hw_in"] = x, (h, w)
+            x, h, w = out, ho, wo
+        self._x_last, self._hw = x, (h, w)
+        f_raw = self.buf("f_raw", B, h, w, self.feat_c)
+        self.final_conv.forward(x, f_raw, bn_scratch=self.partials(f_raw) if fuse else None)
+        bn = self.final_bn
+        bn.stats(f_raw, training, fused=fuse)
+        self._pooled = self._vec("pooled", B, self.feat_c)
+        ops.bn_act_pool(f_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self._pooled, act=ACT)
+        feat = self._pooled
+        self._dropped = training and self.dropout_rate > 0.0
+        if self._dropped:
+            if ("mask", B) not in self._bufs:
+                self._bufs[("mask", B)] = torch.empty((B, self.feat_c), dtype=torch.uint8, device=self.device)
+            self._mask = self._bufs[("mask", B)]
+            feat = self._vec("dropped", B, self.feat_c)
+            self._step += 1
+            ops.dropout_fwd(self._pooled, self.dropout_rate, self.dropout_seed * 1000003 + self._step, self._mask,
+                            feat)
+        self._feat = feat
+        z = self._vec("z", B, self.num_classes)
+        ops.linear_fwd(feat, self.store.p("output.fc.weight"), self.store.p("output.fc.bias"), z)
+        return z
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, gz, comm=None):
+        B = self._B
+        st = self.store
+        buckets = self.grad_buckets() if comm is not None else None
+        gz = gz.contiguous()
+        gfeat = self._vec("gfeat", B, self.feat_c)
+        ops.linear_bwd(self._feat, st.p("output.fc.weight"), gz, gfeat, st.g("output.fc.weight"),
+                       st.g("output.fc.bias"))
+        if self._dropped:
+            gpooled = self._vec("gpooled", B, self.feat_c)
+            ops.dropout_bwd(gfeat, self.dropout_rate, self._mask, gpooled)
+        else:
+            gpooled = gfeat
+        h, w = self._hw
+        f_raw = self.buf("f_raw", B, h, w, self.feat_c)
+        gf = self.buf("g_f", B, h, w, self.feat_c)
+        bn = self.final_bn
+        ops.bn_act_bwd(None, f_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                       st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gf, act=ACT, gpool=gpooled)
+        self.final_conv.backward_weight(self._x_last, gf)
+        g = self.buf(f"g_{self._x_last.shape[3]}_{h}", B, h, w, self._x_last.shape[3])
+        self.final_conv.backward_data(gf, g)
+        for u in reversed(self.units):
+            k, s = u["key"], u["stride"]
+            cin, mid, cout = _pad32(u["cin"]), _pad32(u["mid"]), _pad32(u["cout"])
+            ho, wo = h, w
+            hi, wi = u["hw_in"]
+            tag = ("@" + k) if self.debug_keep else ""
+            p_raw = self.buf(k + ".p_raw", B, ho, wo, cout)
+            d_raw = self.buf(k + ".d_raw", B, ho, wo, mid)
+            d_se = self.buf(k + ".d_se", B, ho, wo, mid)
+            gp = self.buf(f"gp_{cout}_{ho}{tag}", B, ho, wo, cout)
+            gd = self.buf(f"gd_{mid}_{ho}{tag}", B, ho, wo, mid)
+            bn = u["bn3"]
+            ops.bn_act_bwd(g, p_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                           st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gp, act=ops.ACT_NONE)
+            u["conv3"].backward_weight(d_se, gp)
+            u["conv3"].backward_data(gp, gd)
+            # squeeze-and-excitation + BatchNorm/swish of the depthwise output (gd rewritten in place)
+            bn = u["bn2"]
+            dgate, gpool = self._vec(f"dgate{tag}", B, mid), self._vec(f"gpool{tag}", B, mid)
+            ops.bn_act_pool(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, dgate, act=ACT, mul=gd, scale=1.0)
+            u["se"].backward(dgate, self._vec(k + ".gate", B, mid), self._vec(k + ".pre1", B, u["se"].mid),
+                             self._vec(k + ".pooled", B, mid), self._vec("dpre2", B, mid),
+                             self._vec("dpre1", B, u["se"].mid), gpool)
+            ops.bn_act_bwd(gd, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                           st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT,
+                           gate=self._vec(k + ".gate", B, mid), gpool=gpool)
+            x_in = u["x_in"]
+            if u["conv1"] is not None:
+                e_raw = self.buf(k + ".e_raw", B, hi, wi, mid)
+                e_act = self.buf(k + ".e_act", B, hi, wi, mid)
+                ge = self.buf(f"ge_{mid}_{hi}{tag}", B, hi, wi, mid)
+                u["dw"].backward_weight(e_act, gd)
+                u["dw"].backward_data(gd, ge)
+                bn = u["bn1"]
+                ops.bn_act_bwd(ge, e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                               st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), ge, act=ACT)
+                u["conv1"].backward_weight(x_in, ge)
+                if u["residual"]:
+                    # out = bn3(...) + x_in: the unit-output gradient g is also the skip gradient ->
+                    # accumulate the expand conv's data gradient into it in place
+                    u["conv1"].backward_data(ge, g, accumulate=True)
+                    g_in = g
+                else:
+                    g_in = self.buf(f"g_{cin}_{hi}{tag}", B, hi, wi, cin)
+                    u["conv1"].backward_data(ge, g_in)
+            else:
+                g_in = self.buf(f"g_{cin}_{hi}{tag}", B, hi, wi, cin)
+                u["dw"].backward_weight(x_in, gd)
+                u["dw"].backward_data(gd, g_in)
+            u["dbg"] = {"g_out": g, "g_in": g_in, "gp": gp, "gd": gd}
+            g, h, w = g_in, hi, wi
+            if comm is not None and k in ("s5u1", "s3u1"):
+                comm.reduce_range(st.grad, *buckets[0 if k == "s5u1" else 1])
+        bn = self.bn0
+        t0 = self.buf("t0", B, h, w, _pad32(self.stem_c))
+        ops.bn_act_bwd(g, t0, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                       st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), g, act=ACT)
+        ops.stem_wgrad(self._img, g, st.g("features.init_block.conv.conv.weight"), self.stem_c, stride=2)
+        if comm is not None:
+            comm.reduce_range(st.grad, *buckets[2])
+            comm.finish(st.grad)

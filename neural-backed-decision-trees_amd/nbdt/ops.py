@@ -296,15 +296,15 @@ def pool_bn_bwd(gpooled, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbet
                                        ptr(dsum), B, H, W, C, ptr(gx), st))
 
 
-def stem_conv(img, w, out, cout_real):
+def stem_conv(img, w, out, cout_real, stride=1):
     B, _, H, W = img.shape
-    check(lib().nbdt_stem_conv(ptr(img), ptr(w), B, H, W, cout_real, out.shape[3], ptr(out),
+    check(lib().nbdt_stem_conv(ptr(img), ptr(w), B, H, W, cout_real, out.shape[3], stride, ptr(out),
                                stream_ptr(img.device)))
 
 
-def stem_wgrad(img, gy, dw, cout_real):
+def stem_wgrad(img, gy, dw, cout_real, stride=1):
     B, _, H, W = img.shape
-    check(lib().nbdt_stem_wgrad(ptr(img), ptr(gy), B, H, W, cout_real, gy.shape[3], ptr(dw),
+    check(lib().nbdt_stem_wgrad(ptr(img), ptr(gy), B, H, W, cout_real, gy.shape[3], stride, ptr(dw),
                                 stream_ptr(img.device)))
 
 
@@ -324,3 +324,66 @@ def linear_bwd(x, w, gz, gx, gw, gb):
 def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, p_bf16=None):
     check(lib().nbdt_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, momentum, weight_decay, grad_scale,
                               ptr(p_bf16), stream_ptr(p.device)))
+
+
+# ------------------------------------------------------------------------------------------------
+# MBConv pieces (EfficientNet-B0, csrc/effnet.hip)
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+
+
+def bn_act_apply(x, mean, rstd, gamma, beta, y, act=ACT_SWISH, gate=None, residual=None):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_act_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(gate),
+                                  ptr(residual), B, H, W, C, ptr(y), stream_ptr(x.device)))
+
+
+def bn_act_pool(x, mean, rstd, gamma, beta, out, act=ACT_SWISH, mul=None, scale=None):
+    B, H, W, C = _dims(x)
+    scale = 1.0 / (H * W) if scale is None else scale
+    check(lib().nbdt_bn_act_pool(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(mul), scale,
+                                 B, H, W, C, ptr(out), stream_ptr(x.device)))
+
+
+def bn_act_bwd(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx, act=ACT_SWISH, gate=None,
+               gpool=None, gx_add=None):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_act_bwd(ptr(gu), ptr(gate), ptr(gpool), ptr(x), ptr(mean), ptr(rstd), ptr(gamma),
+                                ptr(beta), act, ptr(gx_add), B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma),
+                                ptr(dbeta), ptr(gx), stream_ptr(x.device)))
+
+
+def dwconv_fwd(x, w, y, k, stride):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_dwconv_fwd(ptr(x), ptr(w), B, H, W, C, k, stride, ptr(y), stream_ptr(x.device)))
+
+
+def dwconv_bwd_data(gy, w, gx, k, stride):
+    B, H, W, C = _dims(gx)
+    check(lib().nbdt_dwconv_bwd_data(ptr(gy), ptr(w), B, H, W, C, k, stride, ptr(gx), stream_ptr(gx.device)))
+
+
+def dwconv_bwd_weight(x, gy, dw, k, stride):
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_dwconv_bwd_weight(ptr(x), ptr(gy), B, H, W, C, k, stride, ptr(dw), stream_ptr(x.device)))
+
+
+def se_gate_fwd(pooled, w1, b1, w2, b2, pre1, gate, c_real):
+    B, C = pooled.shape
+    check(lib().nbdt_se_gate_fwd(ptr(pooled), ptr(w1), ptr(b1), ptr(w2), ptr(b2), B, C, c_real, w1.shape[0],
+                                 ptr(pre1), ptr(gate), stream_ptr(pooled.device)))
+
+
+def se_gate_bwd(dgate, gate, pre1, pooled, w1, w2, dpre2, dpre1, gpool, dw1, db1, dw2, db2, c_real):
+    B, C = pooled.shape
+    check(lib().nbdt_se_gate_bwd(ptr(dgate), ptr(gate), ptr(pre1), ptr(pooled), ptr(w1), ptr(w2), B, C, c_real,
+                                 w1.shape[0], ptr(dpre2), ptr(dpre1), ptr(gpool), ptr(dw1), ptr(db1), ptr(dw2),
+                                 ptr(db2), stream_ptr(pooled.device)))
+
+
+def dropout_fwd(x, p, seed, mask, y):
+    check(lib().nbdt_dropout_fwd(ptr(x), x.numel(), p, seed & 0xffffffff, ptr(mask), ptr(y), stream_ptr(x.device)))
+
+
+def dropout_bwd(gy, p, mask, gx):
+    check(lib().nbdt_dropout_bwd(ptr(gy), gy.numel(), p, ptr(mask), ptr(gx), stream_ptr(gy.device)))

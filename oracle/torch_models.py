@@ -184,3 +184,122 @@ class ResNet18(nn.Module):
             out = getattr(self, f"layer{i + 1}")(out)
         out = F.avg_pool2d(out, out.size()[2:]).flatten(1)
         return self.linear(out)
+
+
+# --------------------------------------------------------------------------------------------------
+# EfficientNet-B0: restates pytorchcv's ``efficientnet_b0`` (``get_efficientnet(
+# version="b0", in_size=(224, 224))``, non-TF mode: symmetric padding, bn_eps 1e-5), the third-party
+# model the reference re-exports at nbdt/models/__init__.py:3.  PARITY UNPINNED (pytorchcv absent,
+# unpinned, no golden vectors); pinned here: the published architecture, 5,288,548 parameters for
+# 1000 classes, and pytorchcv's state-dict key names (``output.fc.weight`` is the classifier key
+# the reference itself relies on, nbdt/graph.py:393).
+
+class _Swish(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+class _ConvBlock(nn.Module):
+    """pytorchcv ConvBlock: conv (bias-free) + BatchNorm + optional Swish."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, groups=groups, bias=False)
+        self.bn = nn.BatchNorm2d(cout, eps=1e-5)
+        self.act = act
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return x * torch.sigmoid(x) if self.act else x
+
+
+class _SEBlock(nn.Module):
+    def __init__(self, channels, mid):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, mid, 1, bias=True)
+        self.conv2 = nn.Conv2d(mid, channels, 1, bias=True)
+
+    def forward(self, x):
+        w = x.mean((2, 3), keepdim=True)
+        w = self.conv1(w)
+        w = w * torch.sigmoid(w)
+        w = torch.sigmoid(self.conv2(w))
+        return x * w
+
+
+class _EffiDwsConvUnit(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.residual = cin == cout and stride == 1
+        self.dw_conv = _ConvBlock(cin, cin, 3, stride, groups=cin)
+        self.se = _SEBlock(cin, cin // 4)
+        self.pw_conv = _ConvBlock(cin, cout, 1, act=False)
+
+    def forward(self, x):
+        y = self.pw_conv(self.se(self.dw_conv(x)))
+        return y + x if self.residual else y
+
+
+class _EffiInvResUnit(nn.Module):
+    def __init__(self, cin, cout, k, stride, exp_factor, se_factor=4):
+        super().__init__()
+        self.residual = cin == cout and stride == 1
+        mid = cin * exp_factor
+        self.conv1 = _ConvBlock(cin, mid, 1)
+        self.conv2 = _ConvBlock(mid, mid, k, stride, groups=mid)
+        self.se = _SEBlock(mid, mid // (exp_factor * se_factor))
+        self.conv3 = _ConvBlock(mid, cout, 1, act=False)
+
+    def forward(self, x):
+        y = self.conv3(self.se(self.conv2(self.conv1(x))))
+        return y + x if self.residual else y
+
+
+class _InitBlock(nn.Module):
+    def __init__(self, cout):
+        super().__init__()
+        self.conv = _ConvBlock(3, cout, 3, stride=2)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+EFFNET_B0_STAGES = [
+    # per stage: list of (out_channels, kernel, expansion); stage stride applies to its first unit
+    (1, [(16, 3, 1)]),
+    (2, [(24, 3, 6), (24, 3, 6)]),
+    (2, [(40, 5, 6), (40, 5, 6)]),
+    (2, [(80, 3, 6)] * 3 + [(112, 5, 6)] * 3),
+    (2, [(192, 5, 6)] * 4 + [(320, 3, 6)]),
+]
+
+
+class EfficientNetB0(nn.Module):
+    def __init__(self, num_classes=1000, dropout_rate=0.2):
+        super().__init__()
+        feats = nn.Sequential()
+        feats.add_module("init_block", _InitBlock(32))
+        cin = 32
+        for i, (stride, units) in enumerate(EFFNET_B0_STAGES):
+            stage = nn.Sequential()
+            for j, (cout, k, exp) in enumerate(units):
+                s = stride if j == 0 else 1
+                unit = _EffiDwsConvUnit(cin, cout, s) if i == 0 else _EffiInvResUnit(cin, cout, k, s, exp)
+                stage.add_module(f"unit{j + 1}", unit)
+                cin = cout
+            feats.add_module(f"stage{i + 1}", stage)
+        feats.add_module("final_block", _ConvBlock(cin, 1280, 1))
+        feats.add_module("final_pool", nn.AdaptiveAvgPool2d(1))
+        self.features = feats
+        self.output = nn.Sequential()
+        if dropout_rate > 0.0:
+            self.output.add_module("dropout", nn.Dropout(p=dropout_rate))
+        self.output.add_module("fc", nn.Linear(1280, num_classes))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        return self.output(self.features(x).flatten(1))

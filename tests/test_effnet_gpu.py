@@ -1,0 +1,321 @@
+"""EfficientNet-B0 path: MBConv kernels against plain fp32 PyTorch ops on the
+same bf16-rounded inputs, then the whole engine against the fp32 oracle restatement
+(oracle/torch_models.py::EfficientNetB0) with identical weights.
+
+Tolerances: bf16 outputs within 2^-7 relative (one bf16 ulp = 2^-8) of the fp32 result computed from
+the same bf16 inputs; fp32 reductions 2e-3 relative; end-to-end the same direction/norm criteria as
+the WRN engine (bf16 storage, see test_engine_gpu.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import nbdt_oracle as O
+import torch_models as TM
+
+pytestmark = pytest.mark.gpu
+
+from nbdt import ops  # noqa: E402
+from nbdt.engine import train_step  # noqa: E402
+from nbdt.engine_effnet import EfficientNetEngine  # noqa: E402
+from nbdt.loss import SoftTreeSupLoss  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _padded_from(x_nchw):
+    """fp32 NCHW (already bf16-representable) -> padded NHWC bf16 device buffer."""
+    B, C, H, W = x_nchw.shape
+    t = ops.padded(B, H, W, C, DEV)
+    ops.interior(t).copy_(x_nchw.permute(0, 2, 3, 1).to(DEV))
+    return t
+
+
+def _nchw(t):
+    return ops.interior(t).float().permute(0, 3, 1, 2).cpu()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _close_bf16(got, want, what, rel=2 ** -7, abs_=1e-3):
+    err = (got - want).abs()
+    tol = rel * want.abs() + abs_
+    assert (err <= tol).all(), f"{what}: max err {err.max().item():.4g} at |ref| {want.abs().max().item():.4g}"
+
+
+def _swish(v):
+    return v * torch.sigmoid(v)
+
+
+@pytest.mark.parametrize("k,stride,C,H,W", [(3, 1, 32, 8, 8), (3, 2, 96, 12, 16), (5, 1, 160, 6, 10),
+                                             (5, 2, 64, 16, 8), (3, 1, 672, 4, 4), (5, 2, 1152, 4, 4)])
+def test_depthwise_conv_forward_and_gradients(k, stride, C, H, W):
+    g = torch.Generator().manual_seed(k * 100 + C)
+    B = 3
+    x = _bf(torch.randn(B, C, H, W, generator=g))
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    gy = _bf(torch.randn(B, C, H // stride, W // stride, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride, k // 2, 1, C)
+    y_ref.backward(gy)
+
+    wt = w.view(C, k * k).t().contiguous().to(DEV)          # [taps][C]
+    xp, gyp = _padded_from(x), _padded_from(gy)
+    yp = ops.padded(B, H // stride, W // stride, C, DEV)
+    ops.dwconv_fwd(xp, wt, yp, k, stride)
+    _close_bf16(_nchw(yp), y_ref.detach(), "dw fwd")
+    gxp = ops.padded(B, H, W, C, DEV)
+    ops.dwconv_bwd_data(gyp, wt, gxp, k, stride)
+    _close_bf16(_nchw(gxp), xr.grad, "dw bwd_data")
+    dw = torch.zeros(k * k, C, device=DEV)
+    ops.dwconv_bwd_weight(xp, gyp, dw, k, stride)
+    ops.dwconv_bwd_weight(xp, gyp, dw, k, stride)           # accumulates (+=)
+    want = 2 * wr.grad.view(C, k * k).t()
+    assert (dw.cpu() - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-4
+    # borders of the outputs stay zero
+    assert yp[:, 0].abs().max().item() == 0 and gxp[:, :, 0].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("C,H,W,act", [(32, 8, 8, ops.ACT_SWISH), (96, 5, 7, ops.ACT_SWISH), (160, 4, 4, ops.ACT_NONE),
+                                       (1280, 2, 2, ops.ACT_SWISH), (64, 6, 6, ops.ACT_RELU)])
+def test_bn_act_apply_pool_and_backward_forms(C, H, W, act):
+    g = torch.Generator().manual_seed(C + H)
+    B = 4
+    f = {ops.ACT_SWISH: _swish, ops.ACT_RELU: torch.relu, ops.ACT_NONE: lambda v: v}[act]
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 2 + 0.3)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    gate = torch.rand(B, C, generator=g)
+    res = _bf(torch.randn(B, C, H, W, generator=g))
+    gu = _bf(torch.randn(B, C, H, W, generator=g))
+    gpool = torch.randn(B, C, generator=g)
+    xp = _padded_from(x)
+    mean = torch.empty(C, device=DEV)
+    rstd = torch.empty(C, device=DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * 2048, device=DEV)
+    ops.bn_stats(xp, scratch, mean, rstd)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+
+    def ref_forward(xr, gr, br):
+        return f(F.batch_norm(xr, None, None, gr, br, True, 0.0, 1e-5))
+
+    # apply: plain, gated, gated + residual
+    yp = ops.padded(B, H, W, C, DEV)
+    a_ref = ref_forward(x, gamma, beta)
+    ops.bn_act_apply(xp, mean, rstd, gd, bd, yp, act=act)
+    _close_bf16(_nchw(yp), a_ref, "apply")
+    ops.bn_act_apply(xp, mean, rstd, gd, bd, yp, act=act, gate=gate.to(DEV), residual=_padded_from(res))
+    _close_bf16(_nchw(yp), a_ref * gate[:, :, None, None] + res, "apply gate+res", abs_=4e-3)
+    # pooled mean, and pooled product with an upstream gradient
+    out = torch.full((B, C), 7.0, device=DEV)
+    ops.bn_act_pool(xp, mean, rstd, gd, bd, out, act=act)
+    assert (out.cpu() - a_ref.mean((2, 3))).abs().max().item() < 2e-3
+    ops.bn_act_pool(xp, mean, rstd, gd, bd, out, act=act, mul=_padded_from(gu), scale=1.0)
+    want = (a_ref * gu).sum((2, 3))
+    assert (out.cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+
+    # backward, three forms, against autograd through batch_norm + act (+ SE scaling / pooling)
+    for form in ("plain", "se", "pool"):
+        xr = x.clone().requires_grad_(True)
+        gr = gamma.clone().requires_grad_(True)
+        br = beta.clone().requires_grad_(True)
+        a = ref_forward(xr, gr, br)
+        if form == "plain":
+            a.backward(gu)
+            args = dict(gu=_padded_from(gu))
+        elif form == "se":
+            (a * gate[:, :, None, None]).backward(gu, retain_graph=True)
+            a.mean((2, 3)).backward(gpool)
+            args = dict(gu=_padded_from(gu), gate=gate.to(DEV), gpool=gpool.to(DEV))
+        else:
+            a.mean((2, 3)).backward(gpool)
+            args = dict(gu=None, gpool=gpool.to(DEV))
+        dsum = torch.empty(2 * C, device=DEV)
+        dgamma = torch.zeros(C, device=DEV)
+        dbeta = torch.zeros(C, device=DEV)
+        gx = ops.padded(B, H, W, C, DEV)
+        add = _bf(torch.randn(B, C, H, W, generator=g)) if form != "pool" else None
+        ops.bn_act_bwd(args["gu"], xp, mean, rstd, gd, bd, scratch, dsum, dgamma, dbeta, gx, act=act,
+                       gate=args.get("gate"), gpool=args.get("gpool"),
+                       gx_add=_padded_from(add) if add is not None else None)
+        want_gx = xr.grad + (add if add is not None else 0)
+        scale = want_gx.abs().max().item()
+        assert (_nchw(gx) - want_gx).abs().max().item() < 2e-2 * scale + 1e-3, form
+        assert (dgamma.cpu() - gr.grad).abs().max().item() < 5e-3 * gr.grad.abs().max().item() + 1e-3, form
+        assert (dbeta.cpu() - br.grad).abs().max().item() < 5e-3 * br.grad.abs().max().item() + 1e-3, form
+        assert scratch.abs().max().item() == 0, "scratch must be left zeroed"
+
+
+@pytest.mark.parametrize("C,Cr,S", [(32, 32, 8), (160, 144, 6), (1152, 1152, 48)])
+def test_se_gate_forward_backward(C, Cr, S):
+    g = torch.Generator().manual_seed(C + S)
+    B = 5
+    pooled = torch.zeros(B, C)
+    pooled[:, :Cr] = torch.randn(B, Cr, generator=g)
+    w1 = torch.randn(S, Cr, generator=g) * 0.3
+    b1 = torch.randn(S, generator=g) * 0.1
+    w2 = torch.randn(Cr, S, generator=g) * 0.3
+    b2 = torch.randn(Cr, generator=g) * 0.1
+    dgate = torch.randn(B, C, generator=g)
+    t = [v.clone().requires_grad_(True) for v in (pooled, w1, b1, w2, b2)]
+    pre1 = t[0][:, :Cr] @ t[1].t() + t[2]
+    gate_ref = torch.sigmoid(_swish(pre1) @ t[3].t() + t[4])
+    gate_ref.backward(dgate[:, :Cr])
+
+    d = lambda v: v.to(DEV).contiguous()
+    pre1_d = torch.empty(B, S, device=DEV)
+    gate_d = torch.empty(B, C, device=DEV)
+    ops.se_gate_fwd(d(pooled), d(w1), d(b1), d(w2), d(b2), pre1_d, gate_d, Cr)
+    assert (gate_d.cpu()[:, :Cr] - gate_ref.detach()).abs().max().item() < 1e-5
+    assert Cr == C or gate_d[:, Cr:].abs().max().item() == 0
+    gpool = torch.empty(B, C, device=DEV)
+    grads = [torch.zeros_like(d(v)) for v in (w1, b1, w2, b2)]
+    ops.se_gate_bwd(d(dgate), gate_d, pre1_d, d(pooled), d(w1), d(w2), torch.empty(B, Cr, device=DEV),
+                    torch.empty(B, S, device=DEV), gpool, grads[0], grads[1], grads[2], grads[3], Cr)
+    assert (gpool.cpu()[:, :Cr] - t[0].grad[:, :Cr]).abs().max().item() < 1e-4
+    for got, ref in zip(grads, t[1:]):
+        assert (got.cpu() - ref.grad).abs().max().item() < 1e-4 * max(1.0, ref.grad.abs().max().item())
+
+
+def test_dropout_and_strided_stem():
+    x = torch.randn(64, 1280, device=DEV)
+    mask = torch.empty(64, 1280, dtype=torch.uint8, device=DEV)
+    y = torch.empty_like(x)
+    ops.dropout_fwd(x, 0.2, 123, mask, y)
+    keep = mask.float().mean().item()
+    assert abs(keep - 0.8) < 0.01
+    assert torch.equal(y, x * mask.float() / 0.8) or (y - x * mask.float() / 0.8).abs().max().item() < 1e-6
+    mask2 = torch.empty_like(mask)
+    ops.dropout_fwd(x, 0.2, 124, mask2, y)
+    assert (mask != mask2).float().mean().item() > 0.2           # a different seed is a different mask
+    gx = torch.empty_like(x)
+    ops.dropout_bwd(x, 0.2, mask, gx)
+    assert (gx - x * mask.float() / 0.8).abs().max().item() < 1e-6
+
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 3, 16, 24, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.2
+    ref = F.conv2d(img, w, None, 2, 1)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(DEV)               # [co][r][s][ci]
+    out = ops.padded(2, 8, 12, 32, DEV)
+    ops.stem_conv(img.to(DEV), wk, out, 32, stride=2)
+    _close_bf16(_nchw(out), ref, "stem s2")
+    gy = _bf(torch.randn(2, 32, 8, 12, generator=g))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(img, wr, None, 2, 1).backward(gy)
+    dw = torch.zeros(32, 3, 3, 3, device=DEV)
+    ops.stem_wgrad(img.to(DEV), _padded_from(gy), dw, 32, stride=2)
+    assert (dw.cpu() - wr.grad.permute(0, 2, 3, 1)).abs().max().item() < 2e-3 * wr.grad.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------- engine
+
+def _rel(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _cos(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def test_state_dict_names_shapes_and_param_count():
+    ref = TM.EfficientNetB0(num_classes=1000)
+    eng = EfficientNetEngine(num_classes=1000, device=DEV)
+    sd_e, sd_r = eng.state_dict(), ref.state_dict()
+    assert set(sd_e) == set(sd_r)
+    for k in sd_r:
+        assert tuple(sd_e[k].shape) == tuple(sd_r[k].shape), k
+    n = sum(v.numel() for k, v in eng.named_params("flat").items())
+    assert n == 5288548                                   # published EfficientNet-B0 size
+    eng.load_state_dict(sd_r)
+    back = eng.state_dict()
+    for k, v in sd_r.items():
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(back[k].cpu(), v), k
+
+
+def test_engine_matches_fp32_oracle(pkg_dir):
+    torch.manual_seed(0)
+    C = 1000
+    ref = TM.EfficientNetB0(num_classes=C, dropout_rate=0.0)
+    eng = EfficientNetEngine(num_classes=C, dropout_rate=0.0, device=DEV)
+    eng.load_state_dict(ref.state_dict())
+    otree = O.OracleTree(*O.default_paths("Imagenet1000", "induced-efficientnet_b7b", pkg_dir))
+    crit = SoftTreeSupLoss(dataset="Imagenet1000", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-efficientnet_b7b")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 3, 96, 96, generator=g)
+    y = torch.randint(0, C, (16,), generator=g)
+    ref.train()
+    z_ref = ref(x)
+    loss_ref, dz = O.soft_tree_sup_loss(otree, z_ref.detach().numpy(), y.numpy())
+    z_ref.backward(torch.from_numpy(dz))
+
+    eng.zero_grad()
+    z = eng.forward(x.to(DEV), training=True)
+    loss, gz = crit.loss_and_grad(z, y.to(DEV))
+    eng.backward(gz)
+    torch.cuda.synchronize()
+    scale = z_ref.abs().max().item()
+    zerr = (z.cpu() - z_ref.detach()).abs().max().item()
+    print(f"logits: max err {zerr:.4f} of scale {scale:.4f}, rel-L2 {_rel(z, z_ref.detach()):.4f}; "
+          f"loss {loss.item():.5f} vs {float(loss_ref):.5f}")
+    grads = eng.named_params("grad")
+    report, bad = [], []
+    for name, p in ref.named_parameters():
+        c = _cos(grads[name], p.grad)
+        ratio = grads[name].float().norm().item() / (p.grad.norm().item() + 1e-30)
+        report.append(f"cos {c:.4f} norm-ratio {ratio:.4f} |ref| {p.grad.norm().item():.3e} {name}")
+        if p.grad.norm().item() < 1e-6:
+            # mathematically zero: the shift of a BatchNorm whose output only feeds 1x1 conv -> BatchNorm
+            # (conv3.bn.bias); the oracle holds fp32 cancellation noise, the engine bf16 noise
+            if grads[name].float().norm().item() > 1e-3:
+                bad.append(report[-1])
+        elif not (c > 0.95 and abs(ratio - 1) < 0.15):
+            bad.append(report[-1])
+    print("\n".join(report))
+    # ~80 bf16 storage points between image and logits, each renormalised by a BatchNorm
+    assert _rel(z, z_ref.detach()) < 8e-2 and zerr < 0.15 * scale
+    assert abs(loss.item() - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    assert not bad, "\n".join(bad)
+    # eval mode uses the running statistics the training step just updated
+    ref.eval()
+    with torch.no_grad():
+        ze_ref = ref(x)
+    ze = eng.forward(x.to(DEV), training=False)
+    assert (ze.cpu() - ze_ref).abs().max().item() < 5e-2 * ze_ref.abs().max().item()
+
+
+def test_training_reduces_the_loss_and_full_size_step_runs():
+    eng = EfficientNetEngine(num_classes=1000, device=DEV, seed=1)
+    crit = SoftTreeSupLoss(dataset="Imagenet1000", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-efficientnet_b7b")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, 3, 224, 224, generator=g).to(DEV)
+    y = torch.randint(0, 1000, (16,), generator=g).to(DEV)
+    losses = [train_step(eng, crit, x, y, lr=0.05).item() for _ in range(6)]
+    assert all(math.isfinite(l) for l in losses), losses
+    assert losses[-1] < losses[0], losses
+
+
+def test_facade_module_is_a_drop_in_backbone_for_nbdt():
+    from nbdt.model import HardNBDT, SoftNBDT
+    from nbdt.models import efficientnet_b0
+    net = efficientnet_b0(num_classes=1000, device=DEV)
+    assert "output.fc.weight" in net.state_dict()          # the key reference nbdt/graph.py:393 reads
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    soft = SoftNBDT("Imagenet1000", net, hierarchy="induced-efficientnet_b7b")
+    hard = HardNBDT("Imagenet1000", net, hierarchy="induced-efficientnet_b7b")
+    with torch.no_grad():
+        P = soft(x)
+        Hh = hard(x)
+    assert P.shape == (4, 1000) and abs(P.sum(1) - 1).max().item() < 1e-4
+    assert torch.equal(Hh.sum(1), torch.ones(4, device=DEV))

@@ -217,6 +217,7 @@ int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void*
   const int nt32 = d->cout / 32;
   if (nt32 % 5 == 0) return launch_dma<5>(p, st);
   if (nt32 % 4 == 0) return launch_dma<4>(p, st);
+  if (nt32 % 3 == 0) return launch_dma<3>(p, st);   // 96 / 192 / 672-wide MBConv projections
   if (nt32 % 2 == 0) return launch_dma<2>(p, st);
   return launch_dma<1>(p, st);
 }

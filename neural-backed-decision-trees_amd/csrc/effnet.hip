@@ -11,6 +11,7 @@
 // Algorithmic bytes per element: pool 2, apply/scale 4 (+2 residual), se_bwd_reduce 4,
 // bwd_reduce 4, bwd_apply 6 (+2 gx_add); depthwise fwd 4, bwd_data 4, bwd_weight 4.
 #include "common.h"
+#include <stdlib.h>
 
 using namespace nbdt;
 
@@ -324,6 +325,77 @@ __global__ __launch_bounds__(kThreads) void dw_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// Row-segment form of the depthwise convolution (forward for stride 1|2, and -- with FLIP -- the
+// stride-1 data gradient, which is the same correlation with the kernel rotated by 180 degrees):
+// a thread owns 8 channels x TW consecutive outputs of one row; per kernel row it loads the
+// TW*S + K - S input pixels under them ONCE and feeds each to every output it overlaps
+// (K=5: 7.5 loads per output instead of 25), K x 8 weights of the row in registers.
+template <int K, int S, int TW, bool FLIP>
+__global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restrict__ x,
+                                                          const float* __restrict__ w, DwGeom d, int nseg,
+                                                          int PY, bf16_t* __restrict__ y) {
+  const MbGeom& g = d.out;
+  constexpr int PAD = K / 2, SPAN = TW * S + K - S;
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  const int item = blockIdx.x * PY + py;
+  if (item >= g.H * nseg) return;
+  const int ho = item / nseg;
+  const int wo0 = (item - ho * nseg) * TW;
+  float acc[TW][8];
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const int hi = ho * S + r - PAD;
+    if (hi < -1 || hi > d.Hi) continue;                  // outside even the zero border
+    float wr[K][8];
+#pragma unroll
+    for (int sx = 0; sx < K; ++sx) {
+      const int tap = FLIP ? (K - 1 - r) * K + (K - 1 - sx) : r * K + sx;
+      const float4 w0 = *(const float4*)(w + (size_t)tap * g.C + cx * 8);
+      const float4 w1 = *(const float4*)(w + (size_t)tap * g.C + cx * 8 + 4);
+      wr[sx][0] = w0.x; wr[sx][1] = w0.y; wr[sx][2] = w0.z; wr[sx][3] = w0.w;
+      wr[sx][4] = w1.x; wr[sx][5] = w1.y; wr[sx][6] = w1.z; wr[sx][7] = w1.w;
+    }
+    const bf16_t* xrow = x + (size_t)b * d.imgi + (hi + 1) * d.rowi + g.C + cx * 8;   // + wi * C
+#pragma unroll
+    for (int j = 0; j < SPAN; ++j) {
+      const int wi = wo0 * S - PAD + j;
+      if (wi < -1 || wi > d.Wi) continue;
+      float f[8];
+      unpack8(*(const u32x4_t*)(xrow + wi * g.C), f);
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const int sx = j - t * S;                          // static after unrolling
+        if (sx >= 0 && sx < K) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[t][i] += f[i] * wr[sx][i];
+        }
+      }
+    }
+  }
+  bf16_t* yrow = y + (size_t)b * g.img + (ho + 1) * g.row + g.C + cx * 8;
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+    if (wo0 + t < g.W) *(u32x4_t*)(yrow + (wo0 + t) * g.C) = pack8(acc[t]);
+}
+
+template <int K, int S, bool FLIP>
+static void launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, void* y, hipStream_t st) {
+  const int Wo = d.out.W, Ho = d.out.H;
+  const int tw = (Wo % 7 == 0) ? 7 : (Wo >= 8 ? 8 : 4);
+  const int nseg = (Wo + tw - 1) / tw;
+  int PY = kThreads / d.out.c8;
+  if (PY < 1) PY = 1;
+  if (PY > Ho * nseg) PY = Ho * nseg;
+  const dim3 grid((Ho * nseg + PY - 1) / PY, B), blk(d.out.c8 * PY);
+#define NBDT_GO(TW) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y)
+  if (tw == 7) NBDT_GO(7); else if (tw == 8) NBDT_GO(8); else NBDT_GO(4);
+#undef NBDT_GO
+}
+
 // gx[hi][wi] = sum_{r,s : (hi+pad-r) % stride == 0, ...} gy[(hi+pad-r)/stride][(wi+pad-s)/stride] * w[r][s]
 // `in` = geometry of the INPUT-sized gradient being written
 __global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __restrict__ gy,
@@ -363,49 +435,69 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __r
   }
 }
 
-// dw[r*k+s][c] += sum_{b, output pixels} gy * x[ho*stride + r - pad][wo*stride + s - pad]
-// blockIdx.z = kernel row r: K accumulators x 8 channels per thread
-template <int K>
+// dw[r*K+s][c] += sum_{b, output pixels} gy * x[ho*S + r - pad][wo*S + s - pad]
+// thread = (8-channel chunk, output row ho), blockIdx.z = kernel row r.  The thread walks its row left to
+// right keeping the K input pixels under the current output in registers (a sliding window: S new
+// 16-byte loads per output pixel instead of K), K x 8 fp32 accumulators.
+template <int K, int S>
 __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* __restrict__ x,
-                                                                 const bf16_t* __restrict__ gy, DwGeom d, int ppt,
-                                                                 float* __restrict__ dw) {
+                                                                 const bf16_t* __restrict__ gy, DwGeom d, int PY,
+                                                                 int bchunk, float* __restrict__ dw) {
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
-  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y, r = blockIdx.z;
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, r = blockIdx.z;
+  constexpr int PAD = K / 2;
   float acc[K][8];
 #pragma unroll
   for (int s = 0; s < K; ++s)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[s][i] = 0.f;
-  const int p0 = blockIdx.x * g.PY * ppt + py;
-  for (int q = 0; q < ppt; ++q) {
-    const int p = p0 + q * g.PY;
-    if (p >= g.hw) break;
-    const int ho = (int)fdiv((unsigned)p, g.div_w);
-    const int wo = p - ho * g.W;
-    const int hi = ho * d.stride + r - d.pad;
-    if (hi < 0 || hi >= d.Hi) continue;
-    float fg[8];
-    unpack8(*(const u32x4_t*)(gy + pix_off(g, b, p, cx)), fg);
+  const int ho = blockIdx.x * PY + py;
+  const int hi = ho * S + r - PAD;
+  const int b0 = blockIdx.y * bchunk;
+  const int b1 = b0 + bchunk < g.B ? b0 + bchunk : g.B;
+  if (ho < g.H && hi >= 0 && hi < d.Hi) {
+    for (int b = b0; b < b1; ++b) {    // images of this block's batch chunk: one fold + atomics for all
+      const bf16_t* xrow = x + (size_t)b * d.imgi + (hi + 1) * d.rowi + g.C + cx * 8;   // + wi * C
+      const bf16_t* grow = gy + (size_t)b * g.img + (ho + 1) * g.row + g.C + cx * 8;    // + wo * C
+      float win[K][8];
+      auto fetch = [&](float* dst, int wi) {
+        if (wi >= -1 && wi <= d.Wi) {      // inside the padded row (the border itself is zero)
+          unpack8(*(const u32x4_t*)(xrow + wi * g.C), dst);
+        } else {
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      const int wi = wo * d.stride + s - d.pad;
-      if (wi < 0 || wi >= d.Wi) continue;
-      float f[8];
-      unpack8(*(const u32x4_t*)(x + (size_t)b * d.imgi + (hi + 1) * d.rowi + (wi + 1) * g.C + cx * 8), f);
+          for (int i = 0; i < 8; ++i) dst[i] = 0.f;
+        }
+      };
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[s][i] += fg[i] * f[i];
+      for (int j = 0; j < K; ++j) fetch(win[j], j - PAD);
+      for (int wo = 0; wo < g.W; ++wo) {
+        float fg[8];
+        unpack8(*(const u32x4_t*)(grow + wo * g.C), fg);
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] += fg[i] * win[j][i];
+#pragma unroll
+        for (int j = 0; j + S < K; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) win[j][i] = win[j + S][i];
+        if (wo + 1 < g.W) {
+#pragma unroll
+          for (int j = K - S; j < K; ++j) fetch(win[j], (wo + 1) * S - PAD + j);
+        }
+      }
     }
   }
   float* dst = dw + (size_t)r * K * g.C;
-  block_fold<K>(acc, cx, py, g.c8, g.PY, lds, [&](int s, int c, float v) { atomicAdd(dst + (size_t)s * g.C + c, v); });
+  block_fold<K>(acc, cx, py, g.c8, PY, lds, [&](int s, int c, float v) { atomicAdd(dst + (size_t)s * g.C + c, v); });
 }
 
 // ------------------------------------------------------------------------------------------
 // squeeze-and-excitation gate.  One block per sample.
 //   hidden = swish(W1 pooled + b1)  [S];   gate = sigmoid(W2 hidden + b2)  [Cr];  gate[c >= Cr] = 0
 // W1 [S][Cr], W2 [Cr][S] (the 1x1 convs with bias of pytorchcv SEBlock), pooled/gate rows have stride C.
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled,
+__global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float* __restrict__ pooled,
                                                           const float* __restrict__ w1,
                                                           const float* __restrict__ b1,
                                                           const float* __restrict__ w2,
@@ -415,9 +507,10 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restric
   float* pl = lds;
   float* hl = lds + Cr;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < Cr; c += 256) pl[c] = pooled[(size_t)b * C + c];
+  const int nthr = blockDim.x, nwave = blockDim.x >> 6;
+  for (int c = threadIdx.x; c < Cr; c += nthr) pl[c] = pooled[(size_t)b * C + c];
   __syncthreads();
-  for (int s = wave; s < S; s += 4) {
+  for (int s = wave; s < S; s += nwave) {
     float acc = 0.f;
     for (int c = lane; c < Cr; c += 64) acc += w1[(size_t)s * Cr + c] * pl[c];
 #pragma unroll
@@ -429,7 +522,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restric
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += nthr) {
     float v = 0.f;
     if (c < Cr) {
       float acc = b2[c];
@@ -441,7 +534,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restric
 }
 
 // per sample: dgate[b,c] (= sum_hw gu*a) -> dpre2[b,c], dpre1[b,s], gpool[b,c] (gradient of the pooled mean)
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate,
+__global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restrict__ dgate,
                                                           const float* __restrict__ gate,
                                                           const float* __restrict__ pre1,
                                                           const float* __restrict__ w1,
@@ -452,14 +545,15 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
   float* d2 = lds;
   float* d1 = lds + Cr;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < Cr; c += 256) {
+  const int nthr = blockDim.x, nwave = blockDim.x >> 6;
+  for (int c = threadIdx.x; c < Cr; c += nthr) {
     const float gt = gate[(size_t)b * C + c];
     const float v = dgate[(size_t)b * C + c] * gt * (1.f - gt);
     d2[c] = v;
     dpre2[(size_t)b * Cr + c] = v;
   }
   __syncthreads();
-  for (int s = wave; s < S; s += 4) {
+  for (int s = wave; s < S; s += nwave) {
     float acc = 0.f;
     for (int c = lane; c < Cr; c += 64) acc += w2[(size_t)c * S + s] * d2[c];
 #pragma unroll
@@ -473,7 +567,7 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += nthr) {
     float acc = 0.f;
     if (c < Cr)
       for (int s = 0; s < S; ++s) acc += w1[(size_t)s * Cr + c] * d1[s];
@@ -481,30 +575,36 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restric
   }
 }
 
-// parameter gradients of the two SE projections, summed over the batch (thread per (c, s) pair)
+// parameter gradients of the two SE projections, summed over the batch: thread per (c, s) pair,
+// blockIdx.y = batch chunk (independent loads unrolled; one atomic per output per chunk)
 __global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restrict__ dpre2,
                                                             const float* __restrict__ dpre1,
                                                             const float* __restrict__ pre1,
                                                             const float* __restrict__ pooled, int B, int C, int Cr,
-                                                            int S, float* __restrict__ dw1, float* __restrict__ db1,
-                                                            float* __restrict__ dw2, float* __restrict__ db2) {
+                                                            int S, int bchunk, float* __restrict__ dw1,
+                                                            float* __restrict__ db1, float* __restrict__ dw2,
+                                                            float* __restrict__ db2) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Cr * S) return;
   const int c = idx % Cr, s = idx / Cr;
+  const int b0 = blockIdx.y * bchunk;
+  const int b1 = b0 + bchunk < B ? b0 + bchunk : B;
   float a1 = 0.f, a2 = 0.f, sb1 = 0.f, sb2 = 0.f;
-  for (int b = 0; b < B; ++b) {
+#pragma unroll 4
+  for (int b = b0; b < b1; ++b) {
     const float p = pre1[(size_t)b * S + s];
-    const float h = p * sigmoidf_(p);
     const float e1 = dpre1[(size_t)b * S + s], e2 = dpre2[(size_t)b * Cr + c];
-    a1 += e1 * pooled[(size_t)b * C + c];
+    const float pl = pooled[(size_t)b * C + c];
+    const float h = p * sigmoidf_(p);
+    a1 += e1 * pl;
     a2 += e2 * h;
     sb1 += e1;
     sb2 += e2;
   }
-  dw1[(size_t)s * Cr + c] += a1;
-  dw2[(size_t)c * S + s] += a2;
-  if (c == 0) db1[s] += sb1;
-  if (s == 0) db2[c] += sb2;
+  atomicAdd(dw1 + (size_t)s * Cr + c, a1);
+  atomicAdd(dw2 + (size_t)c * S + s, a2);
+  if (c == 0) atomicAdd(db1 + s, sb1);
+  if (s == 0) atomicAdd(db2 + c, sb2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -662,8 +762,13 @@ extern "C" int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t
   int rc = check_dw(B, H, W, C, k, stride);
   if (rc) return rc;
   const DwGeom d = dw_geom(B, H, W, C, k, stride, 4);
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(d.out.slices, B), dim3(d.out.threads), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, w, d, 4, (bf16_t*)y);
+  hipStream_t st = (hipStream_t)stream;
+  static const bool simple = getenv("NBDT_DW_SIMPLE") != nullptr;   // per-pixel reference kernel (A/B)
+  if (simple)
+    hipLaunchKernelGGL(dw_fwd_kernel, dim3(d.out.slices, B), dim3(d.out.threads), 0, st, (const bf16_t*)x, w, d, 4,
+                       (bf16_t*)y);
+  else if (k == 3) { if (stride == 1) launch_dw_row<3, 1, false>(x, w, d, B, y, st); else launch_dw_row<3, 2, false>(x, w, d, B, y, st); }
+  else { if (stride == 1) launch_dw_row<5, 1, false>(x, w, d, B, y, st); else launch_dw_row<5, 2, false>(x, w, d, B, y, st); }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -674,8 +779,15 @@ extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, i
   int rc = check_dw(B, H, W, C, k, stride);
   if (rc) return rc;
   const MbGeom in = mb_geom(B, H, W, C, 4);
-  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(in.slices, B), dim3(in.threads), 0, (hipStream_t)stream,
-                     (const bf16_t*)gy, w, in, H / stride, W / stride, k, stride, k / 2, 4, (bf16_t*)gx);
+  hipStream_t st = (hipStream_t)stream;
+  static const bool simple = getenv("NBDT_DW_SIMPLE") != nullptr;
+  if (stride == 1 && !simple) {   // same correlation with the kernel rotated by 180 degrees
+    const DwGeom d = dw_geom(B, H, W, C, k, 1, 4);
+    if (k == 3) launch_dw_row<3, 1, true>(gy, w, d, B, gx, st); else launch_dw_row<5, 1, true>(gy, w, d, B, gx, st);
+  } else {
+    hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(in.slices, B), dim3(in.threads), 0, st, (const bf16_t*)gy, w, in,
+                       H / stride, W / stride, k, stride, k / 2, 4, (bf16_t*)gx);
+  }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -685,16 +797,23 @@ extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, 
   NBDT_REQUIRE(x && gy && dw, "null argument");
   int rc = check_dw(B, H, W, C, k, stride);
   if (rc) return rc;
-  const int ppt = 32;
-  const DwGeom d = dw_geom(B, H, W, C, k, stride, ppt);
-  const dim3 grid(d.out.slices, B, k), blk(d.out.threads);
-  const size_t shmem = (size_t)d.out.threads * k * 8 * sizeof(float);
-  if (k == 3)
-    hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, grid, blk, shmem, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)gy, d, ppt, dw);
-  else
-    hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, grid, blk, shmem, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)gy, d, ppt, dw);
+  const DwGeom d = dw_geom(B, H, W, C, k, stride, 1);
+  const int Ho = H / stride;
+  int PY = kThreads / d.out.c8;
+  if (PY < 1) PY = 1;
+  if (PY > Ho) PY = Ho;
+  const int threads = d.out.c8 * PY;
+  // every block ends in c8*k*8 global atomics: let a block walk several images when rows are short
+  int bchunk = 128 / (W / stride);
+  if (bchunk < 1) bchunk = 1;
+  if (bchunk > B) bchunk = B;
+  const dim3 grid((Ho + PY - 1) / PY, (B + bchunk - 1) / bchunk, k), blk(threads);
+  const size_t shmem = (size_t)threads * k * 8 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define NBDT_GO(K, S) hipLaunchKernelGGL((dw_bwd_weight_kernel<K, S>), grid, blk, shmem, st, (const bf16_t*)x, (const bf16_t*)gy, d, PY, bchunk, dw)
+  if (k == 3) { if (stride == 1) NBDT_GO(3, 1); else NBDT_GO(3, 2); }
+  else { if (stride == 1) NBDT_GO(5, 1); else NBDT_GO(5, 2); }
+#undef NBDT_GO
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -704,8 +823,9 @@ extern "C" int nbdt_se_gate_fwd(const float* pooled, const float* w1, const floa
                                 float* gate, void* stream) {
   NBDT_REQUIRE(pooled && w1 && b1 && w2 && b2 && pre1 && gate, "null argument");
   NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
-  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), (size_t)(C_real + S) * sizeof(float),
-                     (hipStream_t)stream, pooled, w1, b1, w2, b2, C, C_real, S, pre1, gate);
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(C_real > 256 ? 1024 : 256),
+                     (size_t)(C_real + S) * sizeof(float), (hipStream_t)stream, pooled, w1, b1, w2, b2, C, C_real, S,
+                     pre1, gate);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -718,12 +838,14 @@ extern "C" int nbdt_se_gate_bwd(const float* dgate, const float* gate, const flo
                "null argument");
   NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), (size_t)(C_real + S) * sizeof(float), st, dgate, gate,
-                     pre1, w1, w2, C, C_real, S, dpre2, dpre1, gpool);
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(C_real > 256 ? 1024 : 256),
+                     (size_t)(C_real + S) * sizeof(float), st, dgate, gate, pre1, w1, w2, C, C_real, S, dpre2, dpre1,
+                     gpool);
   NBDT_LAUNCH_CHECK();
   const int n = C_real * S;
-  hipLaunchKernelGGL(se_param_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dpre2, dpre1, pre1, pooled, B, C,
-                     C_real, S, dw1, db1, dw2, db2);
+  const int bchunk = 16;
+  hipLaunchKernelGGL(se_param_grad_kernel, dim3((n + 255) / 256, (B + bchunk - 1) / bchunk), dim3(256), 0, st, dpre2,
+                     dpre1, pre1, pooled, B, C, C_real, S, bchunk, dw1, db1, dw2, db2);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

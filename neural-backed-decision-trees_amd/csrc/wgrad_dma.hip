@@ -298,11 +298,13 @@ int wgrad_dma(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw
   do {                                   \
     if (nt % 5 == 0) NBDT_WG(WM_, 5);    \
     if (nt % 4 == 0) NBDT_WG(WM_, 4);    \
+    if (nt % 3 == 0) NBDT_WG(WM_, 3);    \
     if (nt % 2 == 0) NBDT_WG(WM_, 2);    \
     NBDT_WG(WM_, 1);                     \
   } while (0)
   if (mt % 5 == 0) NBDT_WG_ROW(5);
   if (mt % 4 == 0) NBDT_WG_ROW(4);
+  if (mt % 3 == 0) NBDT_WG_ROW(3);
   if (mt % 2 == 0) NBDT_WG_ROW(2);
   NBDT_WG_ROW(1);
 #undef NBDT_WG_ROW

@@ -47,16 +47,19 @@ def shard_batch(t, rank, world):
 class GradComm:
     """Bucketed, overlapped sum all-reduce of a flat gradient buffer."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
+        """force=True issues the collectives even in a 1-rank group (exercises the RCCL path on a
+        single-GPU box; see tests/test_dist_gpu.py)."""
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force) and dist.is_initialized()
         self._stream = None
         self._work = []
 
     def reduce_range(self, flat, lo, hi):
         """Launch the all-reduce of flat[lo:hi]; everything already enqueued on the current stream
         that wrote this range is ordered before it."""
-        if self.world_size == 1 or hi <= lo:
+        if (self.world_size == 1 and not self.force) or hi <= lo:
             return
         view = flat[lo:hi]
         if flat.is_cuda:

@@ -122,6 +122,7 @@ struct HaloGeom {
   int a_instr;         // ceil(hp*4 / 64) wave-instructions per halo tile (wave w issues ids w, w+4, ..)
   int a_bytes;         // a_instr * 1024
   int blocks_per_img;  // gh / rb when ib == 1
+  int nwv;             // waves per block: 4 (256-pixel tile) or 8 (512-pixel tile)
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
 struct BnBwdArgs;

@@ -61,11 +61,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 //   2  backward: out = dL/d(relu(bn(x))); with g' = out * [bn(x) > 0]:  sum(g'), sum(g' * xhat)
 //                -> dbeta / dgamma sums of the BatchNorm being differentiated (replaces bn_bwd_reduce:
 //                   the gradient tensor is not re-read, x is read once, coalesced, right here)
-template <int NT, bool HAS_RES, int STATS>
+template <int NT, bool HAS_RES, int STATS, int NWV = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
                                               unsigned char* smem, int m0, int n0, int m_blk, int wave, int lane,
                                               int tid) {
   constexpr int BN = 32 * NT;
+  constexpr int NTHR = 64 * NWV;
   const nbdt_conv_desc& d = p.d;
   const int frag_row = lane & 31;
   const int frag_half = lane >> 5;
@@ -86,13 +87,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   __builtin_amdgcn_s_barrier();          // every wave is done with the K ring
   asm volatile("" ::: "memory");
   unsigned char* region = smem + wave * REGION;
-  int* row_off = (int*)(smem + 4 * REGION) + wave * 64;      // element offset of each of the wave's 64 pixels
-  float* blk_stats = (float*)(smem + 4 * REGION + 4 * 64 * 4);  // [2][BN]
+  int* row_off = (int*)(smem + NWV * REGION) + wave * 64;    // element offset of each of the wave's 64 pixels
+  float* blk_stats = (float*)(smem + NWV * REGION + NWV * 64 * 4);  // [2][BN]
   {
     const int m = m0 + wave * 64 + lane;
     row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
     if (STATS) {
-      for (int i = tid; i < 2 * BN; i += 256) blk_stats[i] = 0.f;
+      for (int i = tid; i < 2 * BN; i += NTHR) blk_stats[i] = 0.f;
       __syncthreads();   // block-uniform: zeroed before any wave's atomics
     }
   }
@@ -207,15 +208,19 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
     __syncthreads();
     // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost
     // more than the separate statistics pass they replace); nbdt_bn_finalize folds the rows
-    float* part = p.stats + (size_t)m_blk * 2 * d.cout;
-    for (int i = tid; i < 2 * BN; i += 256) {
+    // (the fold kernels expect one row per 256 pixels: a 512-pixel tile fills row 2*m_blk and zeroes the next)
+    constexpr int RPB = NWV / 4;
+    float* part = p.stats + (size_t)m_blk * RPB * 2 * d.cout;
+    const bool second = RPB == 2 && (m_blk * RPB + 1) * 256 < p.M;
+    for (int i = tid; i < 2 * BN; i += NTHR) {
       const int which = i / BN, c = i - which * BN;
       part[(size_t)which * d.cout + n0 + c] = blk_stats[i];
+      if (second) part[(size_t)(2 + which) * d.cout + n0 + c] = 0.f;
     }
   }
 }
 
-template <int NT>
+template <int NT, int NWV = 4>
 constexpr int conv_epilogue_lds_bytes() {
-  return 4 * 32 * (2 * 32 * NT + 16) + 4 * 64 * 4 + 2 * 32 * NT * 4;
+  return NWV * 32 * (2 * 32 * NT + 16) + NWV * 64 * 4 + 2 * 32 * NT * 4;
 }

@@ -19,27 +19,42 @@
 // image rows / whole images (32x32, 16x16, 8x8, 64x64, ...): 97% of the backbone's igemm flops.
 #include "conv_common.h"
 
-constexpr int NW_SLOTS = 3;
+#ifndef NBDT_HALO_NWS8
+#define NBDT_HALO_NWS8 3    // weight-ring slots of the 8-wave kernel (prefetch distance = slots - 1)
+#endif
+constexpr int nw_slots(int nwv) { return nwv == 8 ? NBDT_HALO_NWS8 : 3; }
+#ifndef NBDT_HALO_DEBUG
+#define NBDT_HALO_DEBUG 0   // 1: no DMA, 2: no waits/barriers, 4: no MFMA, 8: no LDS fragment reads
+#endif
 
-constexpr int min_w_dma_h(int w_instr) {
+constexpr int min_w_dma_h(int w_instr, int nwv) {
   int best = 1 << 30;
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < nwv; ++w) {
     int n = 0;
-    for (int id = w; id < w_instr; id += 4) ++n;
+    for (int id = w; id < w_instr; id += nwv) ++n;
     best = n < best ? n : best;
   }
   return best;
 }
 
 
-template <int NT, bool HAS_RES, int STATS>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParams p, nbdt::HaloGeom hg) {
+// NWV = waves per block: 4 (256-pixel tile, 2 blocks per CU) or 8 (512-pixel tile, 1 block per CU).
+// Ablation of the 4-wave kernel (compile-time NBDT_HALO_DEBUG variants, 160->160 @ 32x32, same box):
+// MFMA only 125 us, + LDS fragment reads 155, DMA + barriers only 139, everything 280 -- the DMA stream
+// (1.14 GB per launch through L2, 80 % of it the weight tile every 256-pixel block re-fetches per tap) takes
+// as long as the math and does not hide behind it: a wave blocked issuing DMA cannot issue MFMAs.  A
+// 512-pixel tile halves the weight traffic per MFMA and the DMA instructions per wave.
+template <int NT, bool HAS_RES, int STATS, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kernel(nbdt::ConvDmaParams p,
+                                                                                   nbdt::HaloGeom hg) {
   constexpr int BN = 32 * NT;
+  constexpr int BMH = 64 * NWV;                     // pixels per block
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int W_INSTR = W_BYTES / 1024;
-  constexpr int IPW_W = (W_INSTR + 3) / 4;
-  constexpr int MINW = min_w_dma_h(W_INSTR);
-  constexpr int MAX_A_SLOTS = 10;
+  constexpr int IPW_W = (W_INSTR + NWV - 1) / NWV;
+  constexpr int MINW = min_w_dma_h(W_INSTR, NWV);
+  constexpr int MAX_A_SLOTS = NWV == 4 ? 10 : 7;
+  constexpr int NWS = nw_slots(NWV);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [A buf 0][A buf 1][W ring x3]
 
@@ -48,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
   if (item >= p.m_blocks * p.n_blocks) return;
   const int m_blk = item / p.n_blocks;
   const int n_blk = item - m_blk * p.n_blocks;
-  const int m0 = m_blk * BM;
+  const int m0 = m_blk * BMH;
   const int n0 = n_blk * BN;
 
   const int tid = threadIdx.x;
@@ -63,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
   const int w_row_len = d.w_ntaps * cin;
   const int a_bytes = NBDT_PIN(hg.a_bytes);
   const int a_instr = NBDT_PIN(hg.a_instr);
-  const int a_slots = (a_instr - wave + 3) >> 2;     // DMA instructions this wave issues per halo tile
-  const int a_min = a_instr >> 2;                    // fewest any wave issues (for the counted waits)
+  const int a_slots = (a_instr - wave + NWV - 1) / NWV;   // DMA instructions this wave issues per halo tile
+  const int a_min = a_instr / NWV;                        // fewest any wave issues (for the counted waits)
   const int hw2 = NBDT_PIN(hg.hw2), himg = NBDT_PIN(hg.himg), hp_total = NBDT_PIN(hg.hp);
   const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)p.w;
   const bf16_t* in_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(in_u >> 32)) << 32) |
@@ -86,12 +101,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
   }
   (void)img_px;
 
-  // ---- A halo DMA slots: wave-instruction id = wave + 4k covers halo pixels [16*id, 16*id+16)
+  // ---- A halo DMA slots: wave-instruction id = wave + NWV*k covers halo pixels [16*id, 16*id+16)
   const int cpos = lane & 3;
   int a_src[MAX_A_SLOTS];
 #pragma unroll
   for (int k = 0; k < MAX_A_SLOTS; ++k) {
-    int hp = (wave + 4 * k) * 16 + (lane >> 2);
+    int hp = (wave + NWV * k) * 16 + (lane >> 2);
     const int swz = (hp >> 2) & 3;            // swizzle follows the LDS position, not the clamped pixel
     hp = hp < hp_total ? hp : hp_total - 1;   // tail lanes re-fetch the last halo pixel (harmless)
     const int img = hp / himg;
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
   int w_src[IPW_W];
 #pragma unroll
   for (int k = 0; k < IPW_W; ++k) {
-    const int id = wave + 4 * k;
+    const int id = wave + NWV * k;
     int row = id * 16 + (lane >> 2);
     row = row < BN ? row : BN - 1;
     w_src[k] = (n0 + row) * w_row_len + ((cpos ^ ((row >> 2) & 3)) << 3);
@@ -117,14 +132,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
 #pragma unroll
     for (int k = 0; k < MAX_A_SLOTS; ++k)
       if (k < a_slots)   // wave-uniform
-        glds16(in_base + (a_src[k] + kc * BK), __builtin_amdgcn_readfirstlane(dst0 + (wave + 4 * k) * 1024));
+        glds16(in_base + (a_src[k] + kc * BK), __builtin_amdgcn_readfirstlane(dst0 + (wave + NWV * k) * 1024));
   };
   auto issue_w = [&](int slot, int tap, int kc) {
     const int w_k = __builtin_amdgcn_readlane(tap_w_v, tap) + kc * BK;
     const unsigned dst0 = w_ring + slot * W_BYTES;
 #pragma unroll
     for (int k = 0; k < IPW_W; ++k) {
-      const int id = wave + 4 * k;
+      const int id = wave + NWV * k;
       if (id < W_INSTR) glds16(w_base + (w_src[k] + w_k), __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
     }
   };
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
   int hp0[2];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
-    const int pl = wave * 64 + tm * 32 + frag_row;     // pixel inside the 256-pixel tile
+    const int pl = wave * 64 + tm * 32 + frag_row;     // pixel inside the block's pixel tile
     const int per_img = hg.rb * d.gw;
     const int img = pl / per_img;
     const int rem = pl - img * per_img;
@@ -151,7 +166,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
     hp0[tm] = img * himg + r * hw2 + c;
   }
 
+  constexpr int dbg = NBDT_HALO_DEBUG;   // compile-time timing experiments only (scratch/ablate.sh)
+  // (Tried on MI355X and dropped, same box A/B: hoisting all 14 ds_read_b128 of a tap above the DMA issue,
+  //  and a two-register-set software pipeline with the barrier between the two 16-channel halves of a tap --
+  //  neither moved the MFMA+LDS-only time of 165 us: the gap to the MFMA-only 134 us is operand data, not
+  //  LDS latency; the MFMA-only variant multiplies zeros and clocks higher.)
   auto compute = [&](int abuf, int wslot, int tap) {
+    if (dbg & 8) {   // MFMA-only: no LDS reads
+      bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      asm volatile("" : "+v"(z));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z, z, acc[tn][tm], 0, 0, 0);
+      return;
+    }
     const unsigned char* As = smem + abuf * a_bytes;
     const unsigned char* Ws = smem + 2 * a_bytes + wslot * W_BYTES;
     const int tr = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
@@ -172,75 +204,82 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
     }
   };
 
-  // counted wait: everything issued after W(t) may stay in flight
-  auto wait_w = [&](bool a_after) {
-    if (!a_after) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINW) : "memory");
-    } else {
-      switch (a_min) {
-#define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINW + K) : "memory"); break;
-        NBDT_CASE(1) NBDT_CASE(2) NBDT_CASE(3) NBDT_CASE(4) NBDT_CASE(5) NBDT_CASE(6) NBDT_CASE(7) NBDT_CASE(8)
-        NBDT_CASE(9) NBDT_CASE(10)
+  // counted wait: `n` most recent DMA instructions of this wave may stay in flight (immediate operand)
+  auto wait_vm = [&](int n) {
+    switch (n) {
+#define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K) : "memory"); break;
+      NBDT_CASE(1) NBDT_CASE(2) NBDT_CASE(3) NBDT_CASE(4) NBDT_CASE(5) NBDT_CASE(6) NBDT_CASE(7) NBDT_CASE(8)
+      NBDT_CASE(9) NBDT_CASE(10) NBDT_CASE(11) NBDT_CASE(12) NBDT_CASE(13) NBDT_CASE(14) NBDT_CASE(15)
+      NBDT_CASE(16) NBDT_CASE(17) NBDT_CASE(18)
 #undef NBDT_CASE
-        default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINW) : "memory"); break;
-      }
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
     }
   };
 
-  // ---- pipeline
-  issue_a(0, 0);
-  issue_w(0, 0, 0);
-  if (nk > 1) issue_w(1, 1, 0);
+  // ---- pipeline: W tiles are prefetched PD = NWS-1 steps ahead through an NWS-slot ring
+  constexpr int PD = NWS - 1;
+  if (!(dbg & 1)) {
+    issue_a(0, 0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue_w(i, i, 0);     // nk >= 9 > PD: taps 0..PD-1 of slice 0
+  }
   int tap = 0, kc = 0, wslot = 0;
-  bool a_issued_prev = false;   // did the previous step issue an A halo tile (after W(t), before W(t+1))?
+  int a_age = 1 << 20;   // steps since the last A halo tile was issued (it sits between two W tiles in issue order)
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) wait_w(a_issued_prev);
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    a_issued_prev = false;
-    if (tap == 0 && kc + 1 < kchunks) {
-      issue_a((kc + 1) & 1, kc + 1);
-      a_issued_prev = true;
+    if (!(dbg & 2)) {
+      // issued after W(t): W(t+1) .. W(min(t+PD-1, nk-1)), plus an A tile if one was issued in the last PD-1 steps
+      int after = nk - 1 - t;
+      after = after < PD - 1 ? after : PD - 1;
+      int n = after * MINW;
+      if (a_age <= PD - 1 && after > 0) n += a_min;
+      wait_vm(n);
+      __builtin_amdgcn_s_barrier();
     }
-    if (t + 2 < nk) {
-      int t2 = tap + 2, k2 = kc;
+    asm volatile("" ::: "memory");
+    ++a_age;
+    if (tap == 0 && kc + 1 < kchunks && !(dbg & 1)) {
+      issue_a((kc + 1) & 1, kc + 1);
+      a_age = 1;
+    }
+    if (t + PD < nk && !(dbg & 1)) {
+      int t2 = tap + PD, k2 = kc;
       if (t2 >= 9) { t2 -= 9; ++k2; }
-      int s2 = wslot + 2;
-      s2 = s2 >= NW_SLOTS ? s2 - NW_SLOTS : s2;
+      int s2 = wslot + PD;
+      s2 = s2 >= NWS ? s2 - NWS : s2;
       issue_w(s2, t2, k2);
     }
-    compute(kc & 1, wslot, tap);
-    wslot = wslot + 1 == NW_SLOTS ? 0 : wslot + 1;
+    if (!(dbg & 4)) compute(kc & 1, wslot, tap);
+    wslot = wslot + 1 == NWS ? 0 : wslot + 1;
     if (++tap == 9) { tap = 0; ++kc; }
   }
 
-  conv_epilogue<NT, HAS_RES, STATS>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
+  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
 }
 
 namespace nbdt {
 
-template <int NT>
+template <int NT, int NWV>
 static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   constexpr int BN = 32 * NT;
+  constexpr int BMH = 64 * NWV;
   p.n_blocks = p.d.cout / BN;
-  p.m_blocks = (p.M + BM - 1) / BM;
+  p.m_blocks = (p.M + BMH - 1) / BMH;
   const int items = p.m_blocks * p.n_blocks;
   p.per_xcd = (items + 7) / 8;
-  size_t shmem = 2 * (size_t)hg.a_bytes + (size_t)NW_SLOTS * BN * BK * 2;
-  const size_t epi = conv_epilogue_lds_bytes<NT>();
+  size_t shmem = 2 * (size_t)hg.a_bytes + (size_t)nw_slots(NWV) * BN * BK * 2;
+  const size_t epi = conv_epilogue_lds_bytes<NT, NWV>();
   if (shmem < epi) shmem = epi;
   static size_t attr_bytes = 0;
   if (shmem > attr_bytes) {
 #define NBDT_ATTR(R, S)                                                                                     \
-  NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>),         \
+  NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S, NWV>),    \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
     NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
 #undef NBDT_ATTR
     attr_bytes = shmem;
   }
-  const dim3 grid(p.per_xcd * 8), blk(256);
-#define NBDT_GO(R, S) hipLaunchKernelGGL((conv3x3_halo_kernel<NT, R, S>), grid, blk, shmem, st, p, hg)
+  const dim3 grid(p.per_xcd * 8), blk(64 * NWV);
+#define NBDT_GO(R, S) hipLaunchKernelGGL((conv3x3_halo_kernel<NT, R, S, NWV>), grid, blk, shmem, st, p, hg)
   if (p.bn_x != nullptr) NBDT_GO(false, 2);
   else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
   else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
@@ -251,21 +290,17 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
 
 // Returns true (and fills hg) when the descriptor is a dense 3x3 / stride-1 conv whose 256-pixel tiles
 // are whole image rows or whole images, and the halo tile fits in LDS next to the weight ring.
-bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
-  if (d->ntaps != 9 || d->in_base != 0 || d->accumulate) return false;
-  if (d->in_ws != d->cin || d->in_hs != (d->gw + 2) * d->cin || d->in_bs != (d->gh + 2) * d->in_hs) return false;
-  for (int t = 0; t < 9; ++t)
-    if (d->tap_off[t] != (t / 3) * d->in_hs + (t % 3) * d->in_ws) return false;
+static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, HaloGeom* hg) {
   const int gw = d->gw, gh = d->gh;
-  if (gw > 256 || 256 % gw != 0) return false;
+  if (gw > tile || tile % gw != 0) return false;
   int ib, rb;
-  if (gw * gh >= 256) {
-    rb = 256 / gw;
+  if (gw * gh >= tile) {
+    rb = tile / gw;
     if (gh % rb != 0) return false;
     ib = 1;
   } else {
-    if (256 % (gw * gh) != 0) return false;
-    ib = 256 / (gw * gh);
+    if (tile % (gw * gh) != 0) return false;
+    ib = tile / (gw * gh);
     rb = gh;
   }
   hg->ib = ib; hg->rb = rb;
@@ -273,16 +308,31 @@ bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
   hg->himg = (rb + 2) * (gw + 2);
   hg->hp = ib * hg->himg;
   const int instr = (hg->hp * 4 + 63) / 64;
-  if ((instr + 3) / 4 > 10 || instr < 4) return false;
+  if ((instr + nwv - 1) / nwv > (nwv == 4 ? 10 : 7) || instr < nwv) return false;
   hg->a_instr = instr;
   hg->a_bytes = instr * 1024;
   hg->blocks_per_img = ib == 1 ? gh / rb : 1;
-  // 2 blocks per CU: 2 A buffers + weight ring must stay under 80 KiB
+  hg->nwv = nwv;
   const int nt32 = d->cout / 32;
   const int nt = nt32 % 5 == 0 ? 5 : (nt32 % 4 == 0 ? 4 : (nt32 % 2 == 0 ? 2 : 1));
-  if (2 * hg->a_bytes + NW_SLOTS * nt * 32 * BK * 2 > 80 * 1024) return false;
-  (void)M;
-  return true;
+  const int lds = 2 * hg->a_bytes + nw_slots(nwv) * nt * 32 * BK * 2;
+  // 4 waves: 2 blocks per CU (80 KiB each); 8 waves: 1 block per CU
+  return lds <= (nwv == 4 ? 80 : 156) * 1024;
+}
+
+// Returns true (and fills hg) when the descriptor is a dense 3x3 / stride-1 conv whose pixel tiles are
+// whole image rows or whole images, and the halo tile fits in LDS next to the weight ring.  Prefers the
+// 512-pixel / 8-wave form (half the weight-tile traffic per MFMA); NBDT_HALO_W4=1 forces the 256-pixel one.
+bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
+  if (d->ntaps != 9 || d->in_base != 0 || d->accumulate) return false;
+  if (d->in_ws != d->cin || d->in_hs != (d->gw + 2) * d->cin || d->in_bs != (d->gh + 2) * d->in_hs) return false;
+  for (int t = 0; t < 9; ++t)
+    if (d->tap_off[t] != (t / 3) * d->in_hs + (t % 3) * d->in_ws) return false;
+  static const bool w4 = getenv("NBDT_HALO_W4") != nullptr;
+  // the wide tile needs enough tiles to fill the chip (1 block per CU)
+  const long long tiles512 = ((long long)M + 511) / 512 * (d->cout / (32 * (d->cout / 32 % 5 == 0 ? 5 : (d->cout / 32 % 4 == 0 ? 4 : (d->cout / 32 % 2 == 0 ? 2 : 1)))));
+  if (!w4 && tiles512 >= 256 && halo_geom_for(d, 512, 8, hg)) return true;
+  return halo_geom_for(d, 256, 4, hg);
 }
 
 int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
@@ -300,10 +350,16 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.M = M;
   p.debug = 0;
   const int nt32 = d->cout / 32;
-  if (nt32 % 5 == 0) return launch_halo<5>(p, hg, st);
-  if (nt32 % 4 == 0) return launch_halo<4>(p, hg, st);
-  if (nt32 % 2 == 0) return launch_halo<2>(p, hg, st);
-  return launch_halo<1>(p, hg, st);
+  if (hg.nwv == 8) {
+    if (nt32 % 5 == 0) return launch_halo<5, 8>(p, hg, st);
+    if (nt32 % 4 == 0) return launch_halo<4, 8>(p, hg, st);
+    if (nt32 % 2 == 0) return launch_halo<2, 8>(p, hg, st);
+    return launch_halo<1, 8>(p, hg, st);
+  }
+  if (nt32 % 5 == 0) return launch_halo<5, 4>(p, hg, st);
+  if (nt32 % 4 == 0) return launch_halo<4, 4>(p, hg, st);
+  if (nt32 % 2 == 0) return launch_halo<2, 4>(p, hg, st);
+  return launch_halo<1, 4>(p, hg, st);
 }
 
 }  // namespace nbdt

@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 import numpy as np
 import torch
 
-_LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libnbdt_hip.so")
+_LIBPATH = os.environ.get("NBDT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib",
+                                                         "libnbdt_hip.so")   # env: kernel A/B builds only
 _lib = None
 
 NBDT_F32, NBDT_BF16, NBDT_F16 = 0, 1, 2

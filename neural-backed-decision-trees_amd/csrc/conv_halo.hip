@@ -22,7 +22,16 @@
 #ifndef NBDT_HALO_NWS8
 #define NBDT_HALO_NWS8 3    // weight-ring slots of the 8-wave kernel (prefetch distance = slots - 1)
 #endif
-constexpr int nw_slots(int nwv) { return nwv == 8 ? NBDT_HALO_NWS8 : 3; }
+__device__ __forceinline__ void gload16(u32x4_t& dst, const void* p) {   // asynchronous: see the counted waits
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void touch16(u32x4_t& v) { asm volatile("" : "+v"(v)::"memory"); }
+
+#ifndef NBDT_HALO_WREG
+#define NBDT_HALO_WREG 0    // 1: weight tiles go global_load -> VGPR -> ds_write (only the halo uses LDS-DMA);
+                            // measured 3-7 % SLOWER per launch than the all-DMA ring on MI355X -> off
+#endif
+constexpr int nw_slots(int nwv) { return NBDT_HALO_WREG ? 2 : (nwv == 8 ? NBDT_HALO_NWS8 : 3); }
 #ifndef NBDT_HALO_DEBUG
 #define NBDT_HALO_DEBUG 0   // 1: no DMA, 2: no waits/barriers, 4: no MFMA, 8: no LDS fragment reads
 #endif
@@ -216,6 +225,78 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kerne
     }
   };
 
+  if constexpr (NBDT_HALO_WREG) {
+    // ---- weights through registers.  Ablation: with the LDS-DMA instructions merely ISSUED (never waited
+    // for) the loop slows from 165 to 230-250 us -- a wave stuck issuing DMA cannot issue MFMAs -- and 70 % of
+    // the DMA instructions are weight tiles.  Here W(u+2) is fetched with plain global_load_dwordx4 at step u
+    // (two register sets, two steps of latency budget), written to the 2-slot ring with ds_write_b128 at the
+    // top of step u+2 just before that step's barrier; only the halo tile (once per 9 steps) still uses DMA.
+    //   issue order:  ... Wl(u) | A?(u-2) | Wl(u+1) | A?(u-1) | <top of step u>
+    int cnt_w = 0;
+#pragma unroll
+    for (int k = 0; k < IPW_W; ++k) cnt_w += (wave + NWV * k < W_INSTR) ? 1 : 0;
+    u32x4_t wreg[2][IPW_W];
+    auto load_w = [&](int set, int tap_, int kc_) {
+      const int w_k = __builtin_amdgcn_readlane(tap_w_v, tap_) + kc_ * BK;
+#pragma unroll
+      for (int k = 0; k < IPW_W; ++k)
+        if (wave + NWV * k < W_INSTR) gload16(wreg[set][k], w_base + (w_src[k] + w_k));
+    };
+    auto commit_w = [&](int set, int slot) {
+#pragma unroll
+      for (int k = 0; k < IPW_W; ++k) {   // the wait above is only meaningful if the values are taken from here on
+        touch16(wreg[set][k]);
+        const int id = wave + NWV * k;
+        if (id < W_INSTR) *(u32x4_t*)(smem + 2 * a_bytes + slot * W_BYTES + id * 1024 + lane * 16) = wreg[set][k];
+      }
+    };
+    auto wait_n = [&](int n) {
+      switch (n) {
+#define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+        NBDT_CASE(1) NBDT_CASE(2) NBDT_CASE(3) NBDT_CASE(4) NBDT_CASE(5) NBDT_CASE(6) NBDT_CASE(7) NBDT_CASE(8)
+        NBDT_CASE(9) NBDT_CASE(10) NBDT_CASE(11) NBDT_CASE(12) NBDT_CASE(13) NBDT_CASE(14) NBDT_CASE(15)
+        NBDT_CASE(16) NBDT_CASE(17) NBDT_CASE(18) NBDT_CASE(19) NBDT_CASE(20) NBDT_CASE(21) NBDT_CASE(22)
+        NBDT_CASE(23) NBDT_CASE(24) NBDT_CASE(25) NBDT_CASE(26)
+#undef NBDT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    };
+    if (!(dbg & 1)) {
+      issue_a(0, 0);
+      load_w(0, 0, 0);
+      load_w(1, 1, 0);
+    }
+    int tap = 0, kc = 0;
+    int a_prev1 = 0, a_prev2 = 0;      // DMA instructions this wave issued for a halo tile at steps u-1 / u-2
+    auto step = [&](int SET, int u) {   // SET is a literal at both call sites: register sets resolve statically
+      if (!(dbg & 2)) wait_n(a_prev2 + (u + 1 < nk ? cnt_w : 0) + a_prev1);
+      if (!(dbg & 1)) commit_w(SET, SET);
+      if (!(dbg & 2)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("" ::: "memory");
+      a_prev2 = a_prev1;
+      a_prev1 = 0;
+      if (!(dbg & 1)) {
+        if (u + 2 < nk) {
+          int t2 = tap + 2, k2 = kc;
+          if (t2 >= 9) { t2 -= 9; ++k2; }
+          load_w(SET, t2, k2);
+        }
+        if (tap == 0 && kc + 1 < kchunks) {
+          issue_a((kc + 1) & 1, kc + 1);
+          a_prev1 = a_slots;
+        }
+      }
+      if (!(dbg & 4)) compute(kc & 1, SET, tap);
+      if (++tap == 9) { tap = 0; ++kc; }
+    };
+    for (int u = 0; u < nk; u += 2) {
+      step(0, u);
+      if (u + 1 < nk) step(1, u + 1);
+    }
+  } else {
   // ---- pipeline: W tiles are prefetched PD = NWS-1 steps ahead through an NWS-slot ring
   constexpr int PD = NWS - 1;
   if (!(dbg & 1)) {
@@ -252,6 +333,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kerne
     wslot = wslot + 1 == NWS ? 0 : wslot + 1;
     if (++tap == 9) { tap = 0; ++kc; }
   }
+  }  // DMA weight path
 
   conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
 }

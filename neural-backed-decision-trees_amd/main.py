@@ -68,6 +68,9 @@ def build_parser():
     p.add_argument("--tree-supervision-weight", "--tsw", type=float, default=1)
     p.add_argument("--tree-supervision-weight-end", "--tswe", type=float)
     p.add_argument("--tree-supervision-weight-power", "--tswp", type=float)
+    p.add_argument("--tree-start-epochs", "--tse", type=int)            # SoftTreeLoss, nbdt/loss.py:62-80
+    p.add_argument("--tree-update-every-epochs", "--tueve", type=int)
+    p.add_argument("--tree-update-end-epochs", "--tuene", type=int)
     # data source (see module docstring)
     p.add_argument("--data-file", help="torch.save'd dict: train_x, train_y, test_x, test_y")
     p.add_argument("--synthetic", type=int, default=0, help="number of synthetic training samples")
@@ -86,7 +89,7 @@ def generate_checkpoint_fname(dataset, arch, path_graph=None, name="", tree_supe
         fname += f"-lr{lr}"
     if name:
         fname += "-" + name
-    if path_graph and any("TreeSupLoss" in l for l in loss):
+    if path_graph and any("TreeSupLoss" in l for l in loss):   # (SoftTreeLoss does not match: reference quirk)
         fname += "-" + Path(path_graph).stem.replace("graph-", "", 1)
     if len(loss) > 1 or loss[0] != "CrossEntropyLoss":
         fname += f'-{",".join(loss)}'
@@ -111,7 +114,7 @@ def multistep_lr(base_lr, epoch, epochs, gamma=0.1):
     return base_lr * gamma ** sum(epoch >= m for m in milestones)
 
 
-def build_criterion(args, tree):
+def build_criterion(args, tree, net=None, checkpoint_path="./"):
     """reference main.py:191-205: the LAST entry of --loss wraps nn.CrossEntropyLoss()."""
     criterion = nn.CrossEntropyLoss()
     for name in args.loss:
@@ -124,6 +127,11 @@ def build_criterion(args, tree):
                     "xent_weight", "xent_weight_end", "xent_weight_power"):
             if getattr(args, key) is not None:
                 kwargs[key] = getattr(args, key)
+        if name == "SoftTreeLoss":     # mid-training re-induction needs the network and a directory
+            kwargs.update(net=net, arch=args.arch, checkpoint_path=checkpoint_path)
+            for key in ("tree_start_epochs", "tree_update_every_epochs", "tree_update_end_epochs"):
+                if getattr(args, key) is not None:
+                    kwargs[key] = getattr(args, key)
         criterion = cls(**kwargs)
     return criterion
 
@@ -233,7 +241,7 @@ def main(argv=None):
             else:
                 log(f"==> Checkpoint found at {resume_path}")
 
-    criterion = build_criterion(args, tree)
+    criterion = build_criterion(args, tree, net=net, checkpoint_path=checkpoint_path)
     fast = criterion if hasattr(criterion, "loss_and_grad") else _PlainCE(tree)
     rules = ANALYSES[args.analysis](tree=tree) if args.analysis else None
     comm = ndist.GradComm() if world > 1 else None

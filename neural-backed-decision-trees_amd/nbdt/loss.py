@@ -11,7 +11,7 @@ When the wrapped criterion is a default ``nn.CrossEntropyLoss()`` the whole loss
 (autograd-enabled) with the user's criterion, exactly like the reference.
 
 ``HardTreeSupLoss`` (reference :212-257) gets the same treatment (hard_loss_kernel).  ``SoftTreeLoss``
-(mid-training hierarchy re-induction) raises.
+(:269-315) adds mid-training re-induction of the hierarchy (nbdt/graph.py, nbdt/hierarchy.py).
 """
 import torch
 import torch.nn as nn
@@ -233,7 +233,52 @@ class HardTreeSupLoss(TreeSupLoss):
 
 
 class SoftTreeLoss(SoftTreeSupLoss):
-    """reference nbdt/loss.py:269-315 re-induces the hierarchy mid-training (out of scope)."""
+    """reference nbdt/loss.py:269-315: plain cross entropy until `tree_start_epochs`, then soft tree
+    supervision on a hierarchy RE-INDUCED from the network's own classifier weights every
+    `tree_update_every_epochs` epochs (until `tree_update_end_epochs`).  Re-induction is host-side ward
+    clustering (nbdt/graph.py); the kernels pick the new hierarchy up through a fresh tree handle."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("SoftTreeLoss (mid-training hierarchy re-induction) is out of scope")
+    accepts_tree_start_epochs = True
+    accepts_tree_update_every_epochs = True
+    accepts_tree_update_end_epochs = True
+    accepts_arch = True
+    accepts_net = lambda net, **kwargs: net
+    accepts_checkpoint_path = lambda checkpoint_path, **kwargs: checkpoint_path
+
+    def __init__(self, *args, arch=None, checkpoint_path="./", net=None, tree_start_epochs=67,
+                 tree_update_every_epochs=10, tree_update_end_epochs=120, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.start_epochs = tree_start_epochs
+        self.update_every_epochs = tree_update_every_epochs
+        self.update_end_epochs = tree_update_end_epochs
+        self.net = net
+        self.arch = arch
+        self.checkpoint_path = checkpoint_path
+
+    def forward_tree(self, outputs, targets):
+        if self.epochs < self.start_epochs:
+            return self.criterion(outputs, targets)  # regular xent
+        return super().forward_tree(outputs, targets)
+
+    def forward(self, outputs, targets):
+        if self.epochs < self.start_epochs:
+            return TreeSupLoss.forward(self, outputs, targets)
+        return super().forward(outputs, targets)
+
+    def loss_and_grad(self, outputs, targets, grad_scale=1.0):
+        if self.epochs < self.start_epochs:      # w_x*CE + w_t*CE through the same fused kernel
+            self.assert_output_not_nbdt(outputs)
+            xent_weight, tree_weight = self.current_weights()
+            handle = self.tree.device_handle(outputs.device.index)
+            return _C.soft_tree_loss(handle, outputs, targets, float(xent_weight) + float(tree_weight), 0.0,
+                                     grad_scale)
+        return super().loss_and_grad(outputs, targets, grad_scale)
+
+    def set_epoch(self, *args, **kwargs):
+        super().set_epoch(*args, **kwargs)
+        offset = self.epochs - self.start_epochs
+        if offset >= 0 and offset % self.update_every_epochs == 0 and self.epochs < self.update_end_epochs:
+            import os
+            checkpoint_dir = self.checkpoint_path.replace(".pth", "")
+            path_graph = os.path.join(checkpoint_dir, f"graph-epoch{self.epochs}.json")
+            self.tree.update_from_model(self.net, self.arch, self.tree.dataset, path_graph=path_graph)

@@ -232,6 +232,18 @@ class Tree:
         memo[wnid] = frozenset(out)
         return memo[wnid]
 
+    def update_from_model(self, model, arch, dataset, classes=None, path_wnids=None, path_graph=None):
+        """reference nbdt/tree.py:176-190: re-induce the hierarchy from `model`'s classifier weights, write
+        it to `path_graph` and reload this Tree in place (kernel handles are rebuilt lazily)."""
+        from nbdt.hierarchy import generate_hierarchy
+        assert model is not None, "`model` cannot be NoneType"
+        path_graph = generate_hierarchy(dataset=dataset, method="induced", arch=arch, model=model, path=path_graph,
+                                        path_wnids=path_wnids or self.path_wnids)
+        tree = Tree(dataset, path_graph=path_graph, path_wnids=path_wnids or self.path_wnids,
+                    classes=classes or self.classes, hierarchy="induced")
+        self.load_hierarchy(dataset=tree.dataset, path_graph=tree.path_graph, path_wnids=tree.path_wnids,
+                            classes=tree.classes)
+
     @classmethod
     def create_from_args(cls, args, classes=None):
         return cls(args.dataset, args.path_graph, args.path_wnids, classes=classes,

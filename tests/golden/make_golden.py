@@ -22,6 +22,7 @@ Recorded per case (dataset, hierarchy, B, seed):
   hloss, hdz   HardTreeSupLoss(CE)(z,y) and autograd dL/dz nbdt/loss.py:212-257 (+ _w variants)
   node_*       per-inode logits/probs/preds/entropy (forward_nodes) nbdt/model.py:101-123
   tree_*       the reference Tree's index maps (inode order, child->classes) nbdt/tree.py:105-125
+induced_*.npz: build_induced_graph (nbdt/graph.py:402-464) on seeded random classifier weights: node / link order
 """
 import os
 import sys
@@ -188,6 +189,32 @@ def run_case(tag, dataset, hierarchy, B, seed, scale):
           f"({os.path.getsize(path)/1024:.1f} KiB)")
 
 
+def run_induced(tag, dataset, F, seed):
+    """Induced hierarchy from classifier weights (nbdt/graph.py:402-464) on seeded random weights.  The
+    reference's call passes `affinity=` which scikit-learn >= 1.4 renamed to `metric=`: the class it
+    imported is wrapped to translate the keyword, nothing else changes."""
+    import nbdt.graph as RG
+    from sklearn.cluster import AgglomerativeClustering as AC
+    from networkx.readwrite.json_graph import node_link_data
+    from nbdt.thirdparty.wn import get_wnids_from_dataset
+
+    RG.AgglomerativeClustering = lambda affinity="euclidean", **kw: AC(metric=affinity, **kw)
+    wnids = get_wnids_from_dataset(dataset)
+    torch.manual_seed(seed)
+    W = torch.randn(len(wnids), F)
+    G = RG.build_induced_graph(wnids, checkpoint=None, state_dict={"linear.weight": W}, dataset=dataset)
+    data = node_link_data(G)
+    path = os.path.join(HERE, f"induced_{tag}.npz")
+    np.savez_compressed(path, W=W.numpy(), node_ids=np.array([n["id"] for n in data["nodes"]]),
+                        node_labels=np.array([n.get("label", "") for n in data["nodes"]]),
+                        link_source=np.array([l["source"] for l in data["links"]]),
+                        link_target=np.array([l["target"] for l in data["links"]]))
+    print(f"induced {tag}: {len(data['nodes'])} nodes, {len(data['links'])} links -> {os.path.basename(path)}")
+
+
 if __name__ == "__main__":
     for case in CASES:
         run_case(*case)
+    run_induced("cifar10", "CIFAR10", 64, 11)
+    run_induced("cifar100", "CIFAR100", 64, 12)
+    run_induced("tiny200", "TinyImagenet200", 32, 13)

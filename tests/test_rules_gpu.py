@@ -14,7 +14,7 @@ from conftest import GOLDEN_CASES
 pytestmark = pytest.mark.gpu
 
 from nbdt import _C  # noqa: E402
-from nbdt.loss import HardTreeSupLoss, SoftTreeSupLoss  # noqa: E402
+from nbdt.loss import HardTreeSupLoss, SoftTreeLoss, SoftTreeSupLoss  # noqa: E402
 from nbdt.model import (HardEmbeddedDecisionRules, HardNBDT, SoftEmbeddedDecisionRules,  # noqa: E402
                         SoftNBDT)
 from nbdt.tree import Tree  # noqa: E402
@@ -241,3 +241,40 @@ def test_module_api_matches_reference_contracts(pkg_dir):
     l3 = crit3(z.detach(), y)
     lo3, _ = O.soft_tree_sup_loss(otree, z.detach().cpu().numpy(), y.cpu().numpy(), 1.0, 3.0)
     assert abs(l3.item() - lo3) <= 1e-5 * abs(lo3)
+
+
+def test_soft_tree_loss_reinduces_the_hierarchy(tmp_path, pkg_dir):
+    """SoftTreeLoss (reference nbdt/loss.py:269-315): cross entropy before `tree_start_epochs`, then the soft
+    tree loss on a hierarchy induced from the network's own classifier rows."""
+    torch.manual_seed(5)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linear = nn.Linear(32, 10)
+
+    net = Net()
+    crit = SoftTreeLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18", net=net,
+                        arch="ResNet18", checkpoint_path=str(tmp_path / "ckpt-x.pth"), tree_start_epochs=2,
+                        tree_update_every_epochs=2, tree_update_end_epochs=5, tree_supervision_weight=3.0)
+    z = torch.randn(32, 10, device=DEV)
+    y = torch.randint(0, 10, (32,), device=DEV)
+    crit.set_epoch(1, 10)                              # before the start epoch: (w_x + w_t) * CE, weights at progress .1
+    w_x, w_t = crit.current_weights()
+    ce = nn.functional.cross_entropy(z, y).item()
+    assert abs(crit(z, y).item() - (w_x + w_t) * ce) < 1e-5 * ce * (w_x + w_t)
+    l_fast, gz = crit.loss_and_grad(z, y)
+    assert abs(l_fast.item() - (w_x + w_t) * ce) < 1e-5 * ce * (w_x + w_t)
+    before = [n.wnid for n in crit.tree.inodes]
+    crit.set_epoch(2, 10)                              # start epoch: hierarchy re-induced from net.linear.weight
+    assert os.path.exists(tmp_path / "ckpt-x" / "graph-epoch2.json")
+    assert [n.wnid for n in crit.tree.inodes] != before
+    otree = O.OracleTree(str(tmp_path / "ckpt-x" / "graph-epoch2.json"), os.path.join(pkg_dir, "wnids", "CIFAR10.txt"))
+    lo, dzo = O.soft_tree_sup_loss(otree, z.cpu().numpy(), y.cpu().numpy(), 1.0, 3.0)
+    zz = z.clone().requires_grad_(True)
+    l = crit(zz, y)
+    l.backward()
+    assert abs(l.item() - lo) <= 1e-5 * abs(lo)
+    np.testing.assert_allclose(zz.grad.cpu().numpy(), dzo, atol=1e-6, rtol=0)
+    crit.set_epoch(3, 10)                              # not an update epoch: same hierarchy
+    assert not os.path.exists(tmp_path / "ckpt-x" / "graph-epoch3.json")

@@ -41,10 +41,14 @@ struct WgradTapsParams {
 };
 }  // namespace nbdt
 
+#ifndef NBDT_WGT_DEBUG
+#define NBDT_WGT_DEBUG 0   // compile-time timing experiments: 1 no DMA, 2 no waits/barriers, 4 no MFMA/LDS reads
+#endif
 constexpr int KS = 32;
 constexpr int NSTAGE = 3;
 constexpr int XSLOTS = 128;                    // halo slots per ci chunk (hp <= 102 used)
-constexpr int X_BYTES = 4 * XSLOTS * 16;       // 4 chunks (32 cins) x 128 slots x 16 B = 8 KiB
+// x tile: (CX/8) chunks x 128 slots x 16 B = 8 KiB for 32 cins (4 waves), 16 KiB for 64 cins (8 waves)
+constexpr int x_bytes(int nwv) { return (nwv * 8 / 8) * XSLOTS * 16; }
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -59,42 +63,60 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-// DMA instructions: gy = 2*WM ids (2 chunks x 32 px each), x = 8 ids (chunk = id>>1, slots 64*(id&1)..+64).
-// Wave w issues gy ids {w, w+4, ..} and x ids {w, w+4}: x is always 2 per wave.
-constexpr int min_g_dma(int g_instr) {
+// DMA instructions: gy = 2*WM ids (2 chunks x 32 px each), x = 2*NWV ids (chunk = id>>1, slots 64*(id&1)..+64).
+// Wave w issues gy ids {w, w+NWV, ..} and x ids {w, w+NWV}: x is always 2 per wave.
+constexpr int min_g_dma(int g_instr, int nwv) {
   int best = 1 << 30;
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < nwv; ++w) {
     int n = 0;
-    for (int id = w; id < g_instr; id += 4) ++n;
+    for (int id = w; id < g_instr; id += nwv) ++n;
     best = n < best ? n : best;
   }
   return best;
 }
 
-template <int WM>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(nbdt::WgradTapsParams p) {
+// NWV = 4: block = 32*WM couts x 32 cins, 2 blocks per CU.  NWV = 8: 32*WM couts x 64 cins, 1 block per CU --
+// the same gy tile feeds twice the cins.  Ablation (160->160 @32x32, B=512): MFMA+LDS without DMA 193 us, the
+// DMA stream alone 253 us, everything 295 us: the kernel is bound by the 1.5 GB it pulls through L2 into LDS
+// (4x the tensors' size: gy is re-read once per cin block, the x halo is 3.2x its core), so bytes per MFMA
+// are the lever; 64 cins per block cut them by 28 %.
+template <int WM, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_kernel(nbdt::WgradTapsParams p) {
   constexpr int CG = 32 * WM;
+  constexpr int NWN = NWV / 2;                 // 16-cin groups (waves along cin)
+  constexpr int CX = 16 * NWN;
+  constexpr int X_BYTES = x_bytes(NWV);
   constexpr int G_BYTES = (CG / 8) * 512;
   constexpr int STAGE = G_BYTES + X_BYTES;
   constexpr int G_INSTR = CG / 16;
-  constexpr int IPG = (G_INSTR + 3) / 4;
-  constexpr int MINPW = min_g_dma(G_INSTR) + 2;
+  constexpr int IPG = (G_INSTR + NWV - 1) / NWV;
+  constexpr int MINPW = min_g_dma(G_INSTR, NWV) + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const nbdt_wgrad_desc& d = p.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
   if (item >= p.items) return;
+  // tile fastest: the blocks that share one pixel range (same split, different cout/cin tile) are neighbours in
+  // item order, i.e. co-resident on ONE XCD, so its L2 fetches their common gy / x tiles from HBM once.
+  // (split-fastest order spread them over the 8 XCDs: TCC hit rate 27 %, 1.4 GB of HBM reads for 0.36 GB
+  // of tensors.)
+#ifdef NBDT_WGT_SPLIT_FASTEST
   const int split = item % p.splits;
   const int tile = item / p.splits;
+#else
+  const int n_tiles = p.items / p.splits;
+  const int tile = item % n_tiles;
+  const int split = item / n_tiles;
+#endif
   const int co_blk = tile / p.n_ci_blocks;
   const int ci_blk = tile - co_blk * p.n_ci_blocks;
   const int co0 = co_blk * CG;
-  const int ci0 = ci_blk * 32;
+  const int ci0 = ci_blk * CX;
   const int s_begin = split * p.stages_per_split;
   int s_end = s_begin + p.stages_per_split;
   s_end = s_end < p.stages ? s_end : p.stages;
@@ -121,11 +143,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(nbdt::WgradTaps
   const int g_px = (lane & 31) ^ (hi_half << 3);
   const int g_lane_src = (g_px / cs) * g_hs + (g_px % cs) * g_ws + d.g_base + co0 + hi_half * 8;
   // x: instruction id -> chunk id>>1 (8 cins), halo slots 64*(id&1) + lane; odd chunks store slot^8.
-  // wave w issues ids w and w+4: chunks (w>>1) and (w>>1)+2, slot half (w&1) for both
+  // wave w issues ids w and w+NWV: slot half (w&1) for both
   int x_lane_src[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int id = wave + 4 * k;
+    const int id = wave + NWV * k;
     const int chunk = id >> 1;
     int slot = 64 * (id & 1) + lane;
     int hp = (chunk & 1) ? (slot ^ 8) : slot;
@@ -148,12 +170,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(nbdt::WgradTaps
     const unsigned dst0 = lds_base + slot_i * STAGE;
 #pragma unroll
     for (int k = 0; k < IPG; ++k) {
-      const int id = wave + 4 * k;
+      const int id = wave + NWV * k;
       if (id < G_INSTR) glds16(gsrc + id * 16, __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int id = wave + 4 * k;
+      const int id = wave + NWV * k;
       glds16(x_base + (x_stage + x_lane_src[k]), __builtin_amdgcn_readfirstlane(dst0 + G_BYTES + id * 1024));
     }
   };
@@ -206,23 +228,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_taps_kernel(nbdt::WgradTaps
   };
 
   // ---- pipeline (same protocol as wgrad_dma.hip)
-  issue(0, s_begin);
-  if (n_st > 1) issue(1, s_begin + 1);
+  constexpr int dbg = NBDT_WGT_DEBUG;
+  if (!(dbg & 1)) {
+    issue(0, s_begin);
+    if (n_st > 1) issue(1, s_begin + 1);
+  }
   int slot_i = 0;
   for (int t = 0; t < n_st; ++t) {
-    if (t + 1 < n_st) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(dbg & 2)) {
+      if (t + 1 < n_st) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
     }
-    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < n_st) {
+    if (t + 2 < n_st && !(dbg & 1)) {
       int s2 = slot_i + 2;
       s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
       issue(s2, s_begin + t + 2);
     }
-    compute(slot_i);
+    if (!(dbg & 4)) compute(slot_i);
     slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;
   }
 
@@ -255,13 +282,13 @@ bool wgrad_taps_applicable(const nbdt_wgrad_desc* d) {
   return true;
 }
 
-template <int WM>
+template <int WM, int NWV>
 static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   const nbdt_wgrad_desc& d = p.d;
-  p.n_ci_blocks = d.cin / 32;
+  p.n_ci_blocks = d.cin / (8 * NWV);
   const int tiles = (d.cout / (32 * WM)) * p.n_ci_blocks;
   static const int rounds = getenv("NBDT_WGRAD_ROUNDS") ? atoi(getenv("NBDT_WGRAD_ROUNDS")) : 1;
-  int splits = (512 * rounds) / tiles;
+  int splits = ((NWV == 4 ? 512 : 256) * rounds) / tiles;
   const int max_splits = p.stages / 16 > 0 ? p.stages / 16 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -270,14 +297,14 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   p.splits = splits;
   p.items = tiles * splits;
   p.per_xcd = (p.items + 7) / 8;
-  const size_t shmem = (size_t)NSTAGE * ((32 * WM / 8) * 512 + X_BYTES);
+  const size_t shmem = (size_t)NSTAGE * ((32 * WM / 8) * 512 + x_bytes(NWV));
   static bool attr_set = false;
   if (!attr_set) {
-    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM>),
+    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, NWV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_taps_kernel<WM>), dim3(p.per_xcd * 8), dim3(256), shmem, st, p);
+  hipLaunchKernelGGL((conv_wgrad_taps_kernel<WM, NWV>), dim3(p.per_xcd * 8), dim3(64 * NWV), shmem, st, p);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -299,10 +326,19 @@ int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* d
   p.div_spr = make_fastdiv((unsigned)p.stages_per_row);
   p.div_rg = make_fastdiv((unsigned)p.rowgroups);
   const int mt = d->cout / 32;
-  if (mt % 5 == 0) return launch_taps<5>(p, st);
-  if (mt % 4 == 0) return launch_taps<4>(p, st);
-  if (mt % 2 == 0) return launch_taps<2>(p, st);
-  return launch_taps<1>(p, st);
+  // 64 cins per block = 28 % fewer DMA bytes per MFMA, but measured 2-6 % SLOWER than two independent
+  // 4-wave blocks per CU (same-box A/B, 320->320 and 640->640): opt-in for experiments only
+  static const bool w8 = getenv("NBDT_WGRAD_W8") != nullptr;
+  if (w8 && d->cin % 64 == 0) {
+    if (mt % 5 == 0) return launch_taps<5, 8>(p, st);
+    if (mt % 4 == 0) return launch_taps<4, 8>(p, st);
+    if (mt % 2 == 0) return launch_taps<2, 8>(p, st);
+    return launch_taps<1, 8>(p, st);
+  }
+  if (mt % 5 == 0) return launch_taps<5, 4>(p, st);
+  if (mt % 4 == 0) return launch_taps<4, 4>(p, st);
+  if (mt % 2 == 0) return launch_taps<2, 4>(p, st);
+  return launch_taps<1, 4>(p, st);
 }
 
 }  // namespace nbdt

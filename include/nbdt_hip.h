@@ -175,7 +175,8 @@ int nbdt_weight_prep_batched(const float* flat, const int64_t* table, int32_t n_
  * NBDT_BN_SLOTS*2*C fp32 of caller-owned workspace that must be ZERO on entry; every call leaves it
  * zero again (the fold kernel clears what it read), so one zero-initialised buffer serves all layers. */
 #define NBDT_BN_SLOTS 32
-/* batch statistics: save_mean/save_rstd [C]; updates running_mean/var (unbiased var) if non-NULL */
+/* batch statistics: save_mean/save_rstd [C]; updates running_mean/var (unbiased var) if non-NULL.
+ * x == NULL: only fold sums a producer already left in `scratch` (nbdt_dwconv_fwd with bn_scratch). */
 int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps,
                   float momentum, float* running_mean, float* running_var, float* scratch,
                   float* save_mean, float* save_rstd, void* stream);
@@ -248,7 +249,8 @@ int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* gpool, const
 /* depthwise Conv2d(C, C, k in {3,5}, stride in {1,2}, padding k/2, groups=C): x [B][H+2][W+2][C] ->
  * y [B][H/stride+2][W/stride+2][C]; w fp32 [k*k][C] (tap-major); dw accumulated (+=). */
 int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
-                    int32_t stride, void* y, void* stream);
+                    int32_t stride, void* y, float* bn_scratch /* nullable: also accumulate sum(y), sum(y^2)
+                    into the NBDT_BN_SLOTS scratch for nbdt_bn_stats(x = NULL, ...) */, void* stream);
 int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t k, int32_t stride, void* gx, void* stream);
 int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, int32_t H, int32_t W, int32_t C,

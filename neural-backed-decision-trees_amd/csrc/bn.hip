@@ -84,11 +84,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ sc
                                                           float* __restrict__ running_var,
                                                           float* __restrict__ save_mean,
                                                           float* __restrict__ save_rstd) {
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
     float s = 0.f, sq = 0.f;
+#pragma unroll 8
     for (int k = 0; k < kSlots; ++k) {
       s += scratch[((size_t)k * 2 + 0) * C + c];
       sq += scratch[((size_t)k * 2 + 1) * C + c];
+    }
+#pragma unroll 8
+    for (int k = 0; k < kSlots; ++k) {
       scratch[((size_t)k * 2 + 0) * C + c] = 0.f;   // leave the slots zeroed for the next user
       scratch[((size_t)k * 2 + 1) * C + c] = 0.f;
     }
@@ -109,11 +113,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
                                                               float* __restrict__ dsum,
                                                               float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
     float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
     for (int k = 0; k < kSlots; ++k) {
       s0 += scratch[((size_t)k * 2 + 0) * C + c];
       s1 += scratch[((size_t)k * 2 + 1) * C + c];
+    }
+#pragma unroll 8
+    for (int k = 0; k < kSlots; ++k) {
       scratch[((size_t)k * 2 + 0) * C + c] = 0.f;
       scratch[((size_t)k * 2 + 1) * C + c] = 0.f;
     }
@@ -310,18 +318,20 @@ static int check_shape(int B, int H, int W, int C) {
 extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
                              float* running_mean, float* running_var, float* scratch, float* save_mean,
                              float* save_rstd, void* stream) {
-  NBDT_REQUIRE(x && scratch && save_mean && save_rstd, "null argument");
+  NBDT_REQUIRE(scratch && save_mean && save_rstd, "null argument");
   NBDT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats must be both set or both NULL");
   int rc = check_shape(B, H, W, C);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const PadGeom g = make_geom(B, H, W, C);
-  const Layout l = layout_for(C);
-  const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st, (const bf16_t*)x, g,
-                     l.c8, l.py, scratch);
-  NBDT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, (float)g.npix, eps, momentum,
+  if (x != nullptr) {   // x == NULL: the producer (nbdt_dwconv_fwd with bn_scratch) already filled the slots
+    const Layout l = layout_for(C);
+    const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st, (const bf16_t*)x, g,
+                       l.c8, l.py, scratch);
+    NBDT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, (float)g.npix, eps, momentum,
                      running_mean, running_var, save_mean, save_rstd);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
@@ -473,7 +483,7 @@ extern "C" int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, 
                        (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
                        scratch);
   NBDT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -536,7 +546,7 @@ extern "C" int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, cons
                      nullptr, gpooled, nullptr, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
                      scratch);
   NBDT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

@@ -270,11 +270,15 @@ __global__ __launch_bounds__(256) void mb_bwd_finalize_kernel(float* __restrict_
                                                               float* __restrict__ dsum,
                                                               float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
     float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
     for (int k = 0; k < kSlots; ++k) {
       s0 += scratch[((size_t)k * 2 + 0) * C + c];
       s1 += scratch[((size_t)k * 2 + 1) * C + c];
+    }
+#pragma unroll 8
+    for (int k = 0; k < kSlots; ++k) {
       scratch[((size_t)k * 2 + 0) * C + c] = 0.f;   // zero-on-entry contract for the next user
       scratch[((size_t)k * 2 + 1) * C + c] = 0.f;
     }
@@ -330,15 +334,19 @@ __global__ __launch_bounds__(kThreads) void dw_fwd_kernel(const bf16_t* __restri
 // a thread owns 8 channels x TW consecutive outputs of one row; per kernel row it loads the
 // TW*S + K - S input pixels under them ONCE and feeds each to every output it overlaps
 // (K=5: 7.5 loads per output instead of 25), K x 8 weights of the row in registers.
-template <int K, int S, int TW, bool FLIP>
+template <int K, int S, int TW, bool FLIP, bool STATS>
 __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restrict__ x,
                                                           const float* __restrict__ w, DwGeom d, int nseg,
-                                                          int PY, bf16_t* __restrict__ y) {
+                                                          int PY, bf16_t* __restrict__ y,
+                                                          float* __restrict__ stats) {
+  extern __shared__ float lds[];
   const MbGeom& g = d.out;
   constexpr int PAD = K / 2, SPAN = TW * S + K - S;
   const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
-  const int item = blockIdx.x * PY + py;
-  if (item >= g.H * nseg) return;
+  int item = blockIdx.x * PY + py;
+  const bool live = item < g.H * nseg;
+  if (!STATS && !live) return;
+  item = live ? item : 0;                    // STATS: idle threads still take part in the block fold
   const int ho = item / nseg;
   const int wo0 = (item - ho * nseg) * TW;
   float acc[TW][8];
@@ -377,13 +385,32 @@ __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restri
     }
   }
   bf16_t* yrow = y + (size_t)b * g.img + (ho + 1) * g.row + g.C + cx * 8;
+  float st[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st[0][i] = st[1][i] = 0.f;
 #pragma unroll
   for (int t = 0; t < TW; ++t)
-    if (wo0 + t < g.W) *(u32x4_t*)(yrow + (wo0 + t) * g.C) = pack8(acc[t]);
+    if (live && wo0 + t < g.W) {
+      const u32x4_t v = pack8(acc[t]);
+      *(u32x4_t*)(yrow + (wo0 + t) * g.C) = v;
+      if (STATS) {      // batch statistics of the NEXT BatchNorm, from the rounded values it will read
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { st[0][i] += f[i]; st[1][i] += f[i] * f[i]; }
+      }
+    }
+  if (STATS) {
+    const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kSlots - 1);
+    block_fold<2>(st, cx, py, g.c8, PY, lds, [&](int q, int c, float v) {
+      atomicAdd(stats + ((size_t)slot * 2 + q) * g.C + c, v);
+    });
+  }
 }
 
 template <int K, int S, bool FLIP>
-static void launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, void* y, hipStream_t st) {
+static void launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, void* y, float* stats,
+                          hipStream_t st) {
   const int Wo = d.out.W, Ho = d.out.H;
   const int tw = (Wo % 7 == 0) ? 7 : (Wo >= 8 ? 8 : 4);
   const int nseg = (Wo + tw - 1) / tw;
@@ -391,7 +418,12 @@ static void launch_dw_row(const void* x, const float* w, const DwGeom& d, int B,
   if (PY < 1) PY = 1;
   if (PY > Ho * nseg) PY = Ho * nseg;
   const dim3 grid((Ho * nseg + PY - 1) / PY, B), blk(d.out.c8 * PY);
-#define NBDT_GO(TW) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y)
+  const size_t shmem = stats ? (size_t)d.out.c8 * PY * 16 * sizeof(float) : 0;
+#define NBDT_GO(TW)                                                                                              \
+  do {                                                                                                           \
+    if (stats) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, true>), grid, blk, shmem, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats); \
+    else hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, false>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats); \
+  } while (0)
   if (tw == 7) NBDT_GO(7); else if (tw == 8) NBDT_GO(8); else NBDT_GO(4);
 #undef NBDT_GO
 }
@@ -717,7 +749,7 @@ extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* g
 #undef NBDT_GO
     NBDT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(mb_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  hipLaunchKernelGGL(mb_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   {
     const MbGeom g = mb_geom(B, H, W, C, kPpt);
@@ -757,18 +789,19 @@ static DwGeom dw_geom(int B, int H, int W, int C, int k, int stride, int ppt) {
 }
 
 extern "C" int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
-                               int32_t stride, void* y, void* stream) {
+                               int32_t stride, void* y, float* bn_scratch, void* stream) {
   NBDT_REQUIRE(x && w && y, "null argument");
   int rc = check_dw(B, H, W, C, k, stride);
   if (rc) return rc;
   const DwGeom d = dw_geom(B, H, W, C, k, stride, 4);
   hipStream_t st = (hipStream_t)stream;
   static const bool simple = getenv("NBDT_DW_SIMPLE") != nullptr;   // per-pixel reference kernel (A/B)
+  NBDT_REQUIRE(!(simple && bn_scratch), "fused statistics need the row-segment kernel (unset NBDT_DW_SIMPLE)");
   if (simple)
     hipLaunchKernelGGL(dw_fwd_kernel, dim3(d.out.slices, B), dim3(d.out.threads), 0, st, (const bf16_t*)x, w, d, 4,
                        (bf16_t*)y);
-  else if (k == 3) { if (stride == 1) launch_dw_row<3, 1, false>(x, w, d, B, y, st); else launch_dw_row<3, 2, false>(x, w, d, B, y, st); }
-  else { if (stride == 1) launch_dw_row<5, 1, false>(x, w, d, B, y, st); else launch_dw_row<5, 2, false>(x, w, d, B, y, st); }
+  else if (k == 3) { if (stride == 1) launch_dw_row<3, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<3, 2, false>(x, w, d, B, y, bn_scratch, st); }
+  else { if (stride == 1) launch_dw_row<5, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<5, 2, false>(x, w, d, B, y, bn_scratch, st); }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -783,7 +816,7 @@ extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, i
   static const bool simple = getenv("NBDT_DW_SIMPLE") != nullptr;
   if (stride == 1 && !simple) {   // same correlation with the kernel rotated by 180 degrees
     const DwGeom d = dw_geom(B, H, W, C, k, 1, 4);
-    if (k == 3) launch_dw_row<3, 1, true>(gy, w, d, B, gx, st); else launch_dw_row<5, 1, true>(gy, w, d, B, gx, st);
+    if (k == 3) launch_dw_row<3, 1, true>(gy, w, d, B, gx, nullptr, st); else launch_dw_row<5, 1, true>(gy, w, d, B, gx, nullptr, st);
   } else {
     hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(in.slices, B), dim3(in.threads), 0, st, (const bf16_t*)gy, w, in,
                        H / stride, W / stride, k, stride, k / 2, 4, (bf16_t*)gx);

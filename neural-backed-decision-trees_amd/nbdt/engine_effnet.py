@@ -48,8 +48,8 @@ class DepthwiseConv:
         v = self.store._view(buf, self.name).view(self.k, self.k, self.C)
         return v[:, :, :self.c_real].permute(2, 0, 1).unsqueeze(1)      # [C, 1, k, k]
 
-    def forward(self, x, y):
-        ops.dwconv_fwd(x, self.store.p(self.name), y, self.k, self.stride)
+    def forward(self, x, y, bn_scratch=None):
+        ops.dwconv_fwd(x, self.store.p(self.name), y, self.k, self.stride, bn_scratch)
 
     def backward_data(self, gy, gx):
         ops.dwconv_bwd_data(gy, self.store.p(self.name), gx, self.k, self.stride)
@@ -198,9 +198,15 @@ class EfficientNetEngine(_Engine):
                 e_act = x
             d_raw = self.buf(k + ".d_raw", B, ho, wo, mid)
             d_se = self.buf(k + ".d_se", B, ho, wo, mid)
-            u["dw"].forward(e_act, d_raw)
             bn = u["bn2"]
-            bn.stats(d_raw, training)
+            if fuse:   # the depthwise kernel leaves sum / sum-of-squares in the BN slots: fold only
+                u["dw"].forward(e_act, d_raw, bn_scratch=self.scratch(bn.C))
+                ops.bn_stats(d_raw, self.scratch(bn.C), bn.mean, bn.rstd, bn.running_mean, bn.running_var,
+                             slots_filled=True)
+                bn.num_batches_tracked += 1
+            else:
+                u["dw"].forward(e_act, d_raw)
+                bn.stats(d_raw, training)
             pooled, gate = self._vec(k + ".pooled", B, mid), self._vec(k + ".gate", B, mid)
             pre1 = self._vec(k + ".pre1", B, u["se"].mid)
             ops.bn_act_pool(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, pooled, act=ACT)

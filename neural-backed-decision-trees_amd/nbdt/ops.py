@@ -249,9 +249,10 @@ def _dims(t):
 
 
 def bn_stats(x, scratch, save_mean, save_rstd, running_mean=None, running_var=None,
-             eps=BN_EPS, momentum=BN_MOMENTUM):
+             eps=BN_EPS, momentum=BN_MOMENTUM, slots_filled=False):
+    """slots_filled: the producing kernel already accumulated the sums into `scratch` (fold only)."""
     B, H, W, C = _dims(x)
-    check(lib().nbdt_bn_stats(ptr(x), B, H, W, C, eps, momentum, ptr(running_mean), ptr(running_var),
+    check(lib().nbdt_bn_stats(None if slots_filled else ptr(x), B, H, W, C, eps, momentum, ptr(running_mean), ptr(running_var),
                               ptr(scratch), ptr(save_mean), ptr(save_rstd), stream_ptr(x.device)))
 
 
@@ -353,9 +354,11 @@ def bn_act_bwd(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx,
                                 ptr(dbeta), ptr(gx), stream_ptr(x.device)))
 
 
-def dwconv_fwd(x, w, y, k, stride):
+def dwconv_fwd(x, w, y, k, stride, bn_scratch=None):
+    """bn_scratch: the 32-slot BN scratch; the kernel adds sum(y), sum(y^2) (fold with bn_stats(None, ...))."""
     B, H, W, C = _dims(x)
-    check(lib().nbdt_dwconv_fwd(ptr(x), ptr(w), B, H, W, C, k, stride, ptr(y), stream_ptr(x.device)))
+    check(lib().nbdt_dwconv_fwd(ptr(x), ptr(w), B, H, W, C, k, stride, ptr(y), ptr(bn_scratch),
+                                stream_ptr(x.device)))
 
 
 def dwconv_bwd_data(gy, w, gx, k, stride):

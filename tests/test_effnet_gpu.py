@@ -80,6 +80,18 @@ def test_depthwise_conv_forward_and_gradients(k, stride, C, H, W):
     assert (dw.cpu() - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-4
     # borders of the outputs stay zero
     assert yp[:, 0].abs().max().item() == 0 and gxp[:, :, 0].abs().max().item() == 0
+    # fused batch statistics of the output (what the next BatchNorm consumes)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * 2048, device=DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    yp2 = ops.padded(B, H // stride, W // stride, C, DEV)
+    ops.dwconv_fwd(xp, wt, yp2, k, stride, bn_scratch=scratch)
+    ops.bn_stats(yp2, scratch, mean, rstd, slots_filled=True)
+    assert torch.equal(yp2, yp) and scratch.abs().max().item() == 0
+    yq = _nchw(yp)
+    want_mean = yq.mean((0, 2, 3))
+    want_rstd = 1.0 / torch.sqrt(yq.var((0, 2, 3), unbiased=False) + 1e-5)
+    assert (mean.cpu() - want_mean).abs().max().item() < 1e-3 * (1 + want_mean.abs().max().item())
+    assert ((rstd.cpu() - want_rstd).abs() / want_rstd).max().item() < 2e-3
 
 
 @pytest.mark.parametrize("C,H,W,act", [(32, 8, 8, ops.ACT_SWISH), (96, 5, 7, ops.ACT_SWISH), (160, 4, 4, ops.ACT_NONE),

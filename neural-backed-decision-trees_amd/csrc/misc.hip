@@ -179,9 +179,83 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
   }
 }
 
+// Wide heads (EfficientNet: 1280 -> 1000) : LDS-tiled fp32 GEMM, 64x64 outputs per block, 4x4 per thread.
+//   C[i][j] (+)= sum_l A(i,l) * B(l,j) [+ bias[j]];   A(i,l) = A[i*ai + l*al],  B(l,j) = B[l*bl + j*bj]
+// (the one-wave-per-output kernels above took 105 / 204 / 133 us for fwd / dgrad / wgrad at B=128)
+template <bool ACC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long long ai, long long al,
+                                                       const float* __restrict__ Bm, long long bl, long long bj,
+                                                       const float* __restrict__ bias, float* __restrict__ C,
+                                                       int ldc, int M, int N, int L) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int ti = tid >> 4, tj = tid & 15;          // thread owns rows ti*4..+3, cols tj*4..+3
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int l0 = 0; l0 < L; l0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;                 // 1024 elements per operand tile
+      // walk the unit-stride dimension with consecutive threads
+      int ia, la, lb, jb;
+      if (al == 1) { la = e & 15; ia = e >> 4; } else { ia = e & 63; la = e >> 6; }
+      if (bj == 1) { jb = e & 63; lb = e >> 6; } else { lb = e & 15; jb = e >> 4; }
+      const int gi = i0 + ia, gl = l0 + la;
+      As[la][ia] = (gi < M && gl < L) ? A[gi * ai + gl * al] : 0.f;
+      const int gj = j0 + jb, gl2 = l0 + lb;
+      Bs[lb][jb] = (gj < N && gl2 < L) ? Bm[gl2 * bl + gj * bj] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const float4 av = *(const float4*)&As[l][ti * 4];
+      const float4 bv = *(const float4*)&Bs[l][tj * 4];
+      const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += a4[a] * b4[b];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int gi = i0 + ti * 4 + a;
+    if (gi >= M) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int gj = j0 + tj * 4 + b;
+      if (gj >= N) continue;
+      float v = acc[a][b] + (bias ? bias[gj] : 0.f);
+      float* dst = C + (size_t)gi * ldc + gj;
+      *dst = ACC ? *dst + v : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_acc_kernel(const float* __restrict__ g, int B, int N,
+                                                         float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += g[(size_t)b * N + n];
+  out[n] += s;
+}
+
 extern "C" int nbdt_linear_fwd(const float* x, const float* w, const float* b, int32_t B, int32_t K, int32_t N,
                                float* z, void* stream) {
   NBDT_REQUIRE(x && w && z && B > 0 && K > 0 && N > 0, "bad linear arguments");
+  if (N >= 64) {
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((N + 63) / 64, (B + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       x, (long long)K, 1ll, w, 1ll, (long long)K, b, z, N, B, N, K);
+    NBDT_LAUNCH_CHECK();
+    return NBDT_OK;
+  }
   const long long outs = (long long)B * N;
   hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, B,
                      K, N, z);
@@ -193,6 +267,23 @@ extern "C" int nbdt_linear_bwd(const float* x, const float* w, const float* gz, 
                                float* gx, float* gw, float* gb, void* stream) {
   NBDT_REQUIRE(x && w && gz && B > 0 && K > 0 && N > 0, "bad linear arguments");
   hipStream_t st = (hipStream_t)stream;
+  if (N >= 64) {
+    if (gx) {   // gx[B,K] = gz[B,N] w[N,K]
+      hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((K + 63) / 64, (B + 63) / 64), dim3(256), 0, st, gz,
+                         (long long)N, 1ll, w, (long long)K, 1ll, (const float*)nullptr, gx, K, B, K, N);
+      NBDT_LAUNCH_CHECK();
+    }
+    if (gw) {   // gw[N,K] += gz^T[N,B] x[B,K]
+      hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, st, gz, 1ll,
+                         (long long)N, x, (long long)K, 1ll, (const float*)nullptr, gw, K, N, K, B);
+      NBDT_LAUNCH_CHECK();
+      if (gb) {
+        hipLaunchKernelGGL(colsum_acc_kernel, dim3((N + 255) / 256), dim3(256), 0, st, gz, B, N, gb);
+        NBDT_LAUNCH_CHECK();
+      }
+    }
+    return NBDT_OK;
+  }
   if (gx) {
     const long long n = (long long)B * K;
     hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gz, w, B, K, N, gx);

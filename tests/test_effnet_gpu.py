@@ -226,6 +226,28 @@ def test_dropout_and_strided_stem():
     assert (dw.cpu() - wr.grad.permute(0, 2, 3, 1)).abs().max().item() < 2e-3 * wr.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("B,K,N", [(128, 1280, 1000), (37, 200, 65), (5, 64, 64)])
+def test_wide_linear_head(B, K, N):
+    g = torch.Generator().manual_seed(B + N)
+    x = torch.randn(B, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    gz = torch.randn(B, N, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    zr = F.linear(xr, wr, br)
+    zr.backward(gz)
+    z = torch.empty(B, N, device=DEV)
+    ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), z)
+    assert (z.cpu() - zr.detach()).abs().max().item() < 1e-4 * zr.abs().max().item()
+    gx = torch.empty(B, K, device=DEV)
+    gw = torch.ones(N, K, device=DEV)          # accumulated into (+=)
+    gb = torch.ones(N, device=DEV)
+    ops.linear_bwd(x.to(DEV), w.to(DEV), gz.to(DEV), gx, gw, gb)
+    assert (gx.cpu() - xr.grad).abs().max().item() < 1e-4 * xr.grad.abs().max().item()
+    assert (gw.cpu() - 1 - wr.grad).abs().max().item() < 1e-4 * wr.grad.abs().max().item()
+    assert (gb.cpu() - 1 - br.grad).abs().max().item() < 1e-4 * br.grad.abs().max().item()
+
+
 # ---------------------------------------------------------------------------------------- engine
 
 def _rel(a, b):

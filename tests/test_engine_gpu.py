@@ -248,3 +248,24 @@ def test_wrn28_10_full_size_step_runs():
         l1 = E.train_step(eng, crit, x, y, lr=0.02).item()
     assert math.isfinite(l0) and math.isfinite(l1) and l1 < l0, (l0, l1)
     assert torch.isfinite(eng.store.flat).all()
+
+
+def test_hipgraph_captured_step_equals_eager_steps():
+    """engine.GraphedStep: the whole train step replayed from one hipGraph."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18")
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(32, 3, 32, 32, generator=g).to(DEV) for _ in range(4)]
+    ys = [torch.randint(0, 10, (32,), generator=g).to(DEV) for _ in range(4)]
+    # (1) lr = 0: parameters never move, so every replay must reproduce the eager loss of ITS batch
+    eager = E.ResNetEngine(num_classes=10, device=DEV, seed=2)
+    graphed = E.ResNetEngine(num_classes=10, device=DEV, seed=2)
+    step = E.GraphedStep(graphed, crit, xs[0], ys[0], lr=0.0, momentum=0.0, weight_decay=0.0, warmup=2)
+    for x, y in zip(xs, ys):
+        le = E.train_step(eager, crit, x, y, 0.0, 0.0, 0.0).item()
+        lg = step(x, y).item()
+        assert abs(le - lg) < 2e-3 * abs(le), (le, lg)
+    # (2) lr > 0: replays train (same batch: the loss must fall) and move the parameters
+    before = graphed.store.flat.clone()
+    step = E.GraphedStep(graphed, crit, xs[0], ys[0], lr=0.05, warmup=1)
+    losses = [step(xs[0], ys[0]).item() for _ in range(5)]
+    assert losses[-1] < losses[0] and (graphed.store.flat - before).norm().item() > 0

@@ -140,6 +140,13 @@ int nbdt_conv_igemm_stats(const nbdt_conv_desc* d, const void* in, const void* w
 int nbdt_conv_igemm_bnbwd(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                           const void* bn_x, const float* save_mean, const float* save_rstd,
                           const float* gamma, const float* beta, float* bn_partials, void* stream);
+/* inference: eval-mode BatchNorm folded into per-channel scale/shift (scale = gamma/sqrt(running_var+eps),
+ * shift = beta - running_mean*scale) and the activation applied in the conv epilogue:
+ *   out = act(conv(in) * scale[c] + shift[c] [+ residual]),  act: NBDT_ACT_NONE | RELU | SWISH.
+ * Replaces Conv2d -> BatchNorm2d(eval) -> ReLU [-> += shortcut] of nbdt/models/resnet.py:69-74 in ONE launch. */
+int nbdt_conv_igemm_affine(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                           const void* residual, const float* scale, const float* shift, int32_t act,
+                           void* stream);
 
 /* weight gradient (replaces cuDNN wgrad): dw[cout][w_ntaps][cin] fp32 += sum over the pixel grid
  * of gy[pix_g(m)][co] * x[pix_x(m) + tap_off[t]][ci]; split over pixels with fp32 atomics, so dw

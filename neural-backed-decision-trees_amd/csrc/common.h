@@ -106,9 +106,12 @@ bool wgrad_taps_applicable(const nbdt_wgrad_desc* d);
 int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
 
 // conv_dma.hip: LDS-DMA pipelined implicit GEMM (default path of nbdt_conv_igemm)
-struct BnBwdArgs {   // the BatchNorm whose input gradient a dgrad launch produces (epilogue STATS mode 2)
+struct BnBwdArgs {   // epilogue extras: the BatchNorm whose input gradient a dgrad launch produces (STATS mode 2)
   const void* x;
   const float *mean, *rstd, *gamma, *beta;
+  // or (mode 3, inference) a folded eval-mode BatchNorm + activation applied to the conv output
+  const float *aff_scale = nullptr, *aff_shift = nullptr;
+  int aff_act = 0;
 };
 int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
                    float* stats, const BnBwdArgs* bn, int M, hipStream_t st);

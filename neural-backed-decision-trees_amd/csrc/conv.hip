@@ -290,6 +290,19 @@ extern "C" int nbdt_conv_igemm_bnbwd(const nbdt_conv_desc* d, const void* in, co
   return conv_igemm_impl(d, in, w, out, nullptr, bn_partials, stream, &bn);
 }
 
+extern "C" int nbdt_conv_igemm_affine(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
+                                      const void* residual, const float* scale, const float* shift, int32_t act,
+                                      void* stream) {
+  NBDT_REQUIRE(scale && shift, "null scale / shift");
+  NBDT_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  NBDT_REQUIRE(d && !d->accumulate, "the fused inference epilogue is for plain outputs");
+  static const bool v1 = getenv("NBDT_IGEMM_V1") != nullptr;
+  NBDT_REQUIRE(!v1, "the fused inference epilogue needs the LDS-DMA kernels (unset NBDT_IGEMM_V1)");
+  nbdt::BnBwdArgs ep{nullptr, nullptr, nullptr, nullptr, nullptr};
+  ep.aff_scale = scale; ep.aff_shift = shift; ep.aff_act = act;
+  return conv_igemm_impl(d, in, w, out, residual, nullptr, stream, &ep);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight prep: fp32 master [cout][taps][cin] -> bf16 same order (+ optional dgrad copy
 // wd[cin][taps][cout], tap order reversed).  Tiny, memory-bound.

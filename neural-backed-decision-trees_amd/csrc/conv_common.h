@@ -21,6 +21,9 @@ struct ConvDmaParams {
   // STATS == 2 only: the BatchNorm whose input gradient this launch produces (x = its forward input)
   const bf16_t* bn_x;
   const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
+  // STATS == 3 only (inference): out = act(conv * aff_scale[c] + aff_shift[c] [+ residual])
+  const float *aff_scale, *aff_shift;
+  int aff_act;         // 0 none, 1 ReLU, 2 swish
   int M, n_blocks, m_blocks, per_xcd;
   int debug;           // NBDT_IGEMM_DEBUG: timing experiments only (1: no DMA, 2: no waits/barriers, 4: no MFMA)
 };
@@ -61,6 +64,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 //   2  backward: out = dL/d(relu(bn(x))); with g' = out * [bn(x) > 0]:  sum(g'), sum(g' * xhat)
 //                -> dbeta / dgamma sums of the BatchNorm being differentiated (replaces bn_bwd_reduce:
 //                   the gradient tensor is not re-read, x is read once, coalesced, right here)
+//   3  inference: eval-mode BatchNorm (running statistics folded into a per-channel scale/shift) and the
+//                activation applied to the accumulators -- the BatchNorm/activation pass disappears
 template <int NT, bool HAS_RES, int STATS, int NWV = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
                                               unsigned char* smem, int m0, int n0, int m_blk, int wave, int lane,
@@ -92,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   {
     const int m = m0 + wave * 64 + lane;
     row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
-    if (STATS) {
+    if (STATS == 1 || STATS == 2) {
       for (int i = tid; i < 2 * BN; i += NTHR) blk_stats[i] = 0.f;
       __syncthreads();   // block-uniform: zeroed before any wave's atomics
     }
@@ -143,12 +148,26 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
         float v0 = acc[tn][tm][4 * q + 0], v1 = acc[tn][tm][4 * q + 1];
         float v2 = acc[tn][tm][4 * q + 2], v3 = acc[tn][tm][4 * q + 3];
         unsigned char* at = myrow + (tn * 32 + q * 8) * 2;
+        if (STATS == 3) {   // this lane's 4 consecutive couts
+          const int c = n0 + tn * 32 + q * 8 + frag_half * 4;
+          const float4 sc = *(const float4*)(p.aff_scale + c);
+          const float4 sh = *(const float4*)(p.aff_shift + c);
+          v0 = v0 * sc.x + sh.x; v1 = v1 * sc.y + sh.y; v2 = v2 * sc.z + sh.z; v3 = v3 * sc.w + sh.w;
+        }
         if (HAS_RES) {
           const u32x2 r = *(const u32x2*)at;
           v0 += __uint_as_float(r[0] << 16);
           v1 += __uint_as_float(r[0] & 0xffff0000u);
           v2 += __uint_as_float(r[1] << 16);
           v3 += __uint_as_float(r[1] & 0xffff0000u);
+        }
+        if (STATS == 3) {
+          if (p.aff_act == 1) {
+            v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+          } else if (p.aff_act == 2) {
+            v0 = v0 / (1.f + __expf(-v0)); v1 = v1 / (1.f + __expf(-v1));
+            v2 = v2 / (1.f + __expf(-v2)); v3 = v3 / (1.f + __expf(-v3));
+          }
         }
         u32x2 pk;
         pk[0] = pack_bf16x2(v0, v1);
@@ -198,7 +217,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
       }
     }
   }
-  if (STATS) {
+  if (STATS == 1 || STATS == 2) {
     if (walker)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {

@@ -185,12 +185,14 @@ static int launch_dma(ConvDmaParams& p, hipStream_t st) {
   NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<NT, R, S>),           \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
     NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
+    NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
 #undef NBDT_ATTR
     attr_set = true;
   }
   const dim3 grid(p.per_xcd * 8), blk(256);
 #define NBDT_GO(R, S) hipLaunchKernelGGL((conv_igemm_dma_kernel<NT, R, S>), grid, blk, shmem, st, p)
-  if (p.bn_x != nullptr) NBDT_GO(false, 2);
+  if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
+  else if (p.bn_x != nullptr) NBDT_GO(false, 2);
   else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
   else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
 #undef NBDT_GO
@@ -211,6 +213,8 @@ int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void*
   p.bn_x = bn ? (const bf16_t*)bn->x : nullptr;
   p.bn_mean = bn ? bn->mean : nullptr; p.bn_rstd = bn ? bn->rstd : nullptr;
   p.bn_gamma = bn ? bn->gamma : nullptr; p.bn_beta = bn ? bn->beta : nullptr;
+  p.aff_scale = bn ? bn->aff_scale : nullptr; p.aff_shift = bn ? bn->aff_shift : nullptr;
+  p.aff_act = bn ? bn->aff_act : 0;
   p.M = M;
   static const int dbg = getenv("NBDT_IGEMM_DEBUG") ? atoi(getenv("NBDT_IGEMM_DEBUG")) : 0;
   p.debug = dbg;

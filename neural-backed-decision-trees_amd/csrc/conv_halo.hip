@@ -357,12 +357,14 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S, NWV>),    \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
     NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
+    NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
 #undef NBDT_ATTR
     attr_bytes = shmem;
   }
   const dim3 grid(p.per_xcd * 8), blk(64 * NWV);
 #define NBDT_GO(R, S) hipLaunchKernelGGL((conv3x3_halo_kernel<NT, R, S, NWV>), grid, blk, shmem, st, p, hg)
-  if (p.bn_x != nullptr) NBDT_GO(false, 2);
+  if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
+  else if (p.bn_x != nullptr) NBDT_GO(false, 2);
   else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
   else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
 #undef NBDT_GO
@@ -429,6 +431,8 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.bn_x = bn ? (const bf16_t*)bn->x : nullptr;
   p.bn_mean = bn ? bn->mean : nullptr; p.bn_rstd = bn ? bn->rstd : nullptr;
   p.bn_gamma = bn ? bn->gamma : nullptr; p.bn_beta = bn ? bn->beta : nullptr;
+  p.aff_scale = bn ? bn->aff_scale : nullptr; p.aff_shift = bn ? bn->aff_shift : nullptr;
+  p.aff_act = bn ? bn->aff_act : 0;
   p.M = M;
   p.debug = 0;
   const int nt32 = d->cout / 32;

@@ -124,6 +124,14 @@ class Conv:
         B, Hp, Wp, _ = x.shape
         ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, residual, bn_scratch)
 
+    def forward_affine(self, x, out, bn, act=1, residual=None):
+        """Inference: conv + eval-mode BatchNorm `bn` (folded to scale/shift) + activation [+ residual] in one
+        launch (act: 0 none, 1 ReLU, 2 swish)."""
+        B, Hp, Wp, _ = x.shape
+        scale, shift = bn.eval_affine()
+        ops.conv_igemm_affine(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, scale, shift, act,
+                              residual)
+
     def backward_data(self, gout, gin, accumulate=False, bn=None, bn_x=None, partials=None):
         """bn/bn_x/partials: `gin` is dL/d(relu(bn(bn_x))) -- also emit that BatchNorm's backward sums
         (single-launch stride-1 dgrads only)."""
@@ -156,6 +164,15 @@ class BatchNorm:
         self.rstd = torch.empty(self.C, device=dev)
         self.dsum = torch.empty(2 * self.C, device=dev)
         self.owner = scratch_owner
+        self._affine = None            # cached (scale, shift) of the eval-mode transform
+
+    def eval_affine(self):
+        """scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale: two [C] vectors computed
+        once per parameter / running-statistics version (plumbing on parameters, not on the data path)."""
+        if self._affine is None:
+            scale = self.gamma * torch.rsqrt(self.running_var + ops.BN_EPS)
+            self._affine = (scale.contiguous(), (self.beta - self.running_mean * scale).contiguous())
+        return self._affine
 
     @property
     def gamma(self):
@@ -168,6 +185,7 @@ class BatchNorm:
     def stats(self, x, training, fused=False):
         """fused=True: the producing conv's epilogue already wrote per-tile partial sums (fold only)."""
         if training:
+            self._affine = None        # running statistics are about to change
             if fused:
                 ops.bn_finalize(x, self.owner.partials(x), self.mean, self.rstd, self.running_mean,
                                 self.running_var)
@@ -209,6 +227,7 @@ class _Engine:
         self.training = True
         self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
+        self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
 
     def scratch(self, C):
         need = ops.BN_SLOTS * 2 * C
@@ -258,6 +277,8 @@ class _Engine:
         self.refresh_derived_weights()
 
     def refresh_derived_weights(self):
+        for b in self.bns:             # gamma / beta may have changed: drop the folded eval transforms
+            b._affine = None
         ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
@@ -383,9 +404,12 @@ class WRNEngine(_Engine):
             fuse = training and self.fuse_stats
             u["bn1"].stats(x, training, fused=fuse and x_has_stats)
             u["bn1"].apply(x, a1, relu=True)
-            u["conv1"].forward(a1, t, bn_scratch=self.partials(t) if fuse else None)
-            u["bn2"].stats(t, training, fused=fuse)
-            u["bn2"].apply(t, a2, relu=True)
+            if not training and self.fuse_eval:   # conv1 + bn2 + ReLU in one launch (t is never materialised)
+                u["conv1"].forward_affine(a1, a2, u["bn2"], act=1)
+            else:
+                u["conv1"].forward(a1, t, bn_scratch=self.partials(t) if fuse else None)
+                u["bn2"].stats(t, training, fused=fuse)
+                u["bn2"].apply(t, a2, relu=True)
             if u["idconv"] is not None:
                 idn = self.buf(f"idn{cout}", B, ho, wo, cout)
                 u["idconv"].forward(a1, idn)
@@ -556,11 +580,24 @@ class ResNetEngine(_Engine):
         for blk in self.blocks:
             k, s, cin, cout = blk["key"], blk["stride"], blk["cin"], blk["cout"]
             ho, wo = h // s, w // s
-            t1 = self.buf(k + ".t1", B, ho, wo, cout)
             a1 = self.buf(k + ".a1", B, ho, wo, cout)
-            t2 = self.buf(k + ".t2", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
             fuse = training and self.fuse_stats
+            if not training and self.fuse_eval:
+                # inference: every Conv-BN(-ReLU)(+shortcut) group of the BasicBlock is ONE launch
+                blk["conv1"].forward_affine(x, a1, blk["bn1"], act=1)
+                if blk["sconv"] is not None:
+                    sc = self.buf(f"sc{cout}", B, ho, wo, cout)
+                    blk["sconv"].forward_affine(x, sc, blk["sbn"], act=0)
+                    res = sc
+                else:
+                    res = x
+                blk["conv2"].forward_affine(a1, out, blk["bn2"], act=1, residual=res)
+                blk["x_in"] = x
+                x, h, w = out, ho, wo
+                continue
+            t1 = self.buf(k + ".t1", B, ho, wo, cout)     # raw conv outputs: only the training path keeps them
+            t2 = self.buf(k + ".t2", B, ho, wo, cout)
             scr = self.partials(t1) if fuse else None
             blk["conv1"].forward(x, t1, bn_scratch=scr)
             blk["bn1"].stats(t1, training, fused=fuse)

@@ -190,10 +190,13 @@ class EfficientNetEngine(_Engine):
             if u["conv1"] is not None:
                 e_raw = self.buf(k + ".e_raw", B, h, w, mid)
                 e_act = self.buf(k + ".e_act", B, h, w, mid)
-                u["conv1"].forward(x, e_raw, bn_scratch=self.partials(e_raw) if fuse else None)
-                bn = u["bn1"]
-                bn.stats(e_raw, training, fused=fuse)
-                ops.bn_act_apply(e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, e_act, act=ACT)
+                if not training and self.fuse_eval:   # expand conv + BN + swish in one launch
+                    u["conv1"].forward_affine(x, e_act, u["bn1"], act=2)
+                else:
+                    u["conv1"].forward(x, e_raw, bn_scratch=self.partials(e_raw) if fuse else None)
+                    bn = u["bn1"]
+                    bn.stats(e_raw, training, fused=fuse)
+                    ops.bn_act_apply(e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, e_act, act=ACT)
             else:
                 e_act = x
             d_raw = self.buf(k + ".d_raw", B, ho, wo, mid)
@@ -214,11 +217,14 @@ class EfficientNetEngine(_Engine):
             ops.bn_act_apply(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, d_se, act=ACT, gate=gate)
             p_raw = self.buf(k + ".p_raw", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
-            u["conv3"].forward(d_se, p_raw, bn_scratch=self.partials(p_raw) if fuse else None)
-            bn = u["bn3"]
-            bn.stats(p_raw, training, fused=fuse)
-            ops.bn_act_apply(p_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, out, act=ops.ACT_NONE,
-                             residual=x if u["residual"] else None)
+            if not training and self.fuse_eval:       # project conv + BN (+ skip) in one launch
+                u["conv3"].forward_affine(d_se, out, u["bn3"], act=0, residual=x if u["residual"] else None)
+            else:
+                u["conv3"].forward(d_se, p_raw, bn_scratch=self.partials(p_raw) if fuse else None)
+                bn = u["bn3"]
+                bn.stats(p_raw, training, fused=fuse)
+                ops.bn_act_apply(p_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, out, act=ops.ACT_NONE,
+                                 residual=x if u["residual"] else None)
             u["x_in"], u["hw_in"] = x, (h, w)
             x, h, w = out, ho, wo
         self._x_last, self._hw = x, (h, w)

@@ -213,6 +213,12 @@ def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, part
         ev[1].record()
 
 
+def conv_igemm_affine(desc, inp, w_bf16, out, scale, shift, act=1, residual=None):
+    """Inference launch: out = act(conv * scale[c] + shift[c] [+ residual]) (act: 0 none, 1 ReLU, 2 swish)."""
+    check(lib().nbdt_conv_igemm_affine(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
+                                       ptr(scale), ptr(shift), act, stream_ptr(inp.device)))
+
+
 def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, gx, gx_add=None):
     """BatchNorm(+ReLU) backward when the producing dgrad already left the reduction partials."""
     B, H, W, C = _dims(x)

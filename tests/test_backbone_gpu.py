@@ -349,3 +349,36 @@ def test_sgd_matches_torch_optim():
         ops.sgd_step(pd, grad.to(DEV), buf, 0.1, 0.9, 5e-4, 1.0, pb)
     np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(pb.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("H,cin,cout,k,stride,act,res", [(16, 64, 64, 3, 1, 1, True), (16, 64, 128, 3, 2, 1, False),
+                                                          (16, 64, 128, 1, 2, 0, False), (8, 96, 160, 1, 1, 2, True),
+                                                          (32, 160, 160, 3, 1, 1, False)])
+def test_conv_with_folded_batchnorm_epilogue(H, cin, cout, k, stride, act, res):
+    """nbdt_conv_igemm_affine: Conv2d -> BatchNorm2d(eval) -> activation [-> += shortcut] in one launch."""
+    g = torch.Generator().manual_seed(H + cin + cout)
+    B = 4 if H >= 32 else 8
+    x = torch.randn(B, cin, H, H, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(torch.bfloat16).float()
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    Ho = H // stride
+    r = torch.randn(B, cout, Ho, Ho, generator=g).to(torch.bfloat16).float() if res else None
+    ref = F.conv2d(x, w, None, stride, k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if res:
+        ref = ref + r
+    ref = {0: lambda v: v, 1: torch.relu, 2: lambda v: v * torch.sigmoid(v)}[act](ref)
+    xp = ops.padded(B, H, H, cin, DEV)
+    ops.interior(xp).copy_(x.permute(0, 2, 3, 1).to(DEV))
+    rp = None
+    if res:
+        rp = ops.padded(B, Ho, Ho, cout, DEV)
+        ops.interior(rp).copy_(r.permute(0, 2, 3, 1).to(DEV))
+    wk = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin).contiguous().to(DEV).to(torch.bfloat16)
+    out = ops.padded(B, Ho, Ho, cout, DEV)
+    d = ops.conv_fwd_desc(B, H, H, cin, cout, k, stride)
+    ops.conv_igemm_affine(d, xp, wk, out, scale.to(DEV), shift.to(DEV), act, rp)
+    got = ops.interior(out).float().permute(0, 3, 1, 2).cpu()
+    err = (got - ref).abs()
+    assert (err <= 2 ** -7 * ref.abs() + 2e-2).all(), err.max().item()
+    assert out[:, 0].abs().max().item() == 0

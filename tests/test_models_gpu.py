@@ -128,3 +128,36 @@ def test_wrn_facade_names_and_forward():
     with torch.no_grad():
         P = soft(torch.randn(4, 3, 32, 32).to(DEV))
     np.testing.assert_allclose(P.sum(1).cpu().numpy(), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("arch", ["ResNet18", "wrn", "efficientnet_b0"])
+def test_fused_inference_path_equals_the_unfused_one(arch):
+    """Eval-mode BatchNorm folded into the conv epilogues (engine.fuse_eval) vs separate BN passes."""
+    from nbdt.engine import ResNetEngine, WRNEngine, train_step
+    from nbdt.engine_effnet import EfficientNetEngine
+    from nbdt.loss import SoftTreeSupLoss
+    import torch.nn as nn
+    if arch == "ResNet18":
+        eng, ds, h, size, C = ResNetEngine(10, device=DEV, seed=1), "CIFAR10", "induced-ResNet18", 32, 10
+    elif arch == "wrn":
+        eng, ds, h, size, C = WRNEngine(10, blocks=10, width_factor=2, device=DEV, seed=1), "CIFAR10", "induced-wrn28_10_cifar10", 32, 10
+    else:
+        eng, ds, h, size, C = EfficientNetEngine(1000, device=DEV, seed=1), "Imagenet1000", "induced-efficientnet_b7b", 64, 1000
+    crit = SoftTreeSupLoss(dataset=ds, criterion=nn.CrossEntropyLoss(), hierarchy=h)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, 3, size, size, generator=g).to(DEV)
+    y = torch.randint(0, C, (16,), generator=g).to(DEV)
+    for _ in range(3):                                    # make the running statistics non-trivial
+        train_step(eng, crit, x, y, 0.02)
+    eng.fuse_eval = True
+    zf = eng.forward(x, training=False).clone()
+    eng.fuse_eval = False
+    zu = eng.forward(x, training=False).clone()
+    scale = zu.abs().max().item()
+    assert (zf - zu).abs().max().item() < 3e-2 * scale, ((zf - zu).abs().max().item(), scale)
+    assert (zf.argmax(1) == zu.argmax(1)).float().mean().item() >= 0.9
+    # a further training step invalidates the folded transforms
+    train_step(eng, crit, x, y, 0.02)
+    eng.fuse_eval = True
+    z2 = eng.forward(x, training=False)
+    assert (z2 - zf).abs().max().item() > 0

@@ -147,7 +147,16 @@ class Conv:
 
     def backward_weight(self, x, gout):
         B, Hp, Wp, _ = x.shape
-        ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name))
+        side = getattr(self, "side_stream", None)
+        if side is None:
+            ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name))
+            return
+        # the weight gradient only feeds the optimizer, so it runs on a second stream next to the
+        # data-gradient chain (see WRNEngine.backward for the buffer-reuse ordering)
+        main = torch.cuda.current_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name))
 
 
 class BatchNorm:
@@ -228,6 +237,7 @@ class _Engine:
         self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
+        self._side = None         # second stream for weight gradients (WRNEngine turns it on)
 
     def scratch(self, C):
         need = ops.BN_SLOTS * 2 * C
@@ -252,8 +262,15 @@ class _Engine:
 
     def conv(self, name, cin, cout, k, stride, init="kaiming_a0"):
         c = Conv(self.store, name, cin, cout, k, stride, self.gen, init)
+        if self._side is not None:
+            c.side_stream = self._side
         self.convs.append(c)
         return c
+
+    def join_side_stream(self):
+        """Order every weight-gradient launch issued on the side stream before what follows on the main one."""
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def bn(self, name, c):
         b = BatchNorm(self.store, name, c, self)
@@ -283,6 +300,7 @@ class _Engine:
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
         """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights."""
+        self.join_side_stream()
         s = self.store
         ops.sgd_step(s.flat, s.grad, s.mom, lr, momentum, weight_decay, grad_scale, s.bf16)
         self.refresh_derived_weights()
@@ -381,6 +399,15 @@ class WRNEngine(_Engine):
         self.store.add("output.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.finalize()
         self._img = None
+        # Weight gradients on a second HIP stream: a wgrad block (55 KB LDS, 4 waves) and a 256-pixel igemm block
+        # (76 KB, 4 waves) fit on one CU together, and the two kernels stall on different things, so running
+        # conv.wgrad next to the dgrad / BatchNorm-backward chain instead of in front of it is worth 3.9 % of the
+        # step (21.62 -> 20.80 ms, same-box A/B; NBDT_NO_WGRAD_STREAM=1 restores the single-stream order).
+        import os
+        if not os.environ.get("NBDT_NO_WGRAD_STREAM"):
+            self._side = torch.cuda.Stream(device=self.device)
+            for c in self.convs:
+                c.side_stream = self._side
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, img, training=None):
@@ -454,6 +481,11 @@ class WRNEngine(_Engine):
                         st.g(pb.name + ".weight"), st.g(pb.name + ".bias"), g)
         toggle = 0
         for u in reversed(self.units):
+            # Gradient buffers are shared between units (gt_*, the two g_in_* ping-pong buffers): a weight
+            # gradient of the PREVIOUS unit still running on the side stream may be reading what this unit is
+            # about to overwrite.  Joining here orders it first; it was issued a whole unit (~0.9 ms) ago and
+            # takes ~0.25 ms, so the wait is free.  Inside one unit no kernel overwrites a wgrad operand.
+            self.join_side_stream()
             k, s = u["key"], u["stride"]
             cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
             ho, wo = h, w
@@ -493,8 +525,10 @@ class WRNEngine(_Engine):
                 u["bn1"].backward(ga1, None, u["x_in"], g_in, relu=True, gx_add=g)
             g, h, w = g_in, hi, wi
             if comm is not None and u["key"] in ("s3u1", "s2u1"):
+                self.join_side_stream()
                 comm.reduce_range(st.grad, *buckets[0 if u["key"] == "s3u1" else 1])
         ops.stem_wgrad(self._img, g, st.g("features.init_block.weight"), self.stem_c)
+        self.join_side_stream()      # every gradient is complete on the caller's stream when backward returns
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])
             comm.finish(st.grad)
@@ -544,6 +578,11 @@ class ResNetEngine(_Engine):
         self.store.add("linear.weight", (num_classes, cin), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.store.add("linear.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.finalize()
+        import os
+        if not os.environ.get("NBDT_NO_WGRAD_STREAM"):     # weight gradients on a second stream (see WRNEngine)
+            self._side = torch.cuda.Stream(device=self.device)
+            for c in self.convs:
+                c.side_stream = self._side
         dev = self.device
         # identity "BN" for the plain average-pool head (features are already post-ReLU)
         self._id_mean = torch.zeros(cin, device=dev)
@@ -640,6 +679,7 @@ class ResNetEngine(_Engine):
                                            self.feat_c, ptr(g), ops.stream_ptr(self.device)))
         toggle = 0
         for blk in reversed(self.blocks):
+            self.join_side_stream()      # shared gradient buffers: see WRNEngine.backward
             k, s, cin, cout = blk["key"], blk["stride"], blk["cin"], blk["cout"]
             ho, wo = h, w
             hi, wi = ho * s, wo * s
@@ -676,10 +716,12 @@ class ResNetEngine(_Engine):
             blk["dbg"] = {"g_out": g, "g_in": g_in}
             g, h, w = g_in, hi, wi
             if comm is not None and k in ("l3b0", "l2b0"):
+                self.join_side_stream()
                 comm.reduce_range(st.grad, *buckets[0 if k == "l3b0" else 1])
         gt0 = self.buf("gt0", B, h, w, 64)
         self.bn0.backward(g, None, self.buf("t0", B, h, w, 64), gt0, relu=True)
         ops.stem_wgrad(self._img, gt0, st.g("conv1.weight"), 64)
+        self.join_side_stream()
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])
             comm.finish(st.grad)

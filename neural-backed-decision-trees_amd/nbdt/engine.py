@@ -296,7 +296,14 @@ class _Engine:
     def refresh_derived_weights(self):
         for b in self.bns:             # gamma / beta may have changed: drop the folded eval transforms
             b._affine = None
-        ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
+        if self._side is None:
+            ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
+            return
+        # the transposed copies are only read by data-gradient launches: build them on the second stream while
+        # the next forward runs (backward() joins the stream before its first dgrad)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
         """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights."""
@@ -468,6 +475,7 @@ class WRNEngine(_Engine):
         """Accumulates d(loss)/d(params) into the flat gradient buffer given gz = dloss/dz [B, classes].
         With a GradComm, each stage's gradient bucket is all-reduced as soon as it is complete."""
         B = self._B
+        self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         buckets = self.grad_buckets() if comm is not None else None
         gz = gz.contiguous()
         st = self.store
@@ -664,6 +672,7 @@ class ResNetEngine(_Engine):
 
     def backward(self, gz, comm=None):
         B = self._B
+        self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         gz = gz.contiguous()
         st = self.store
         buckets = self.grad_buckets() if comm is not None else None
@@ -763,6 +772,7 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = train_step(engine, criterion, self.img, self.targets, lr, momentum, weight_decay)
+            engine.join_side_stream()     # a capture must end with every forked stream joined
 
     def __call__(self, img, targets):
         self.img.copy_(img, non_blocking=True)

@@ -121,6 +121,8 @@ typedef struct nbdt_conv_desc {
   int32_t in_bs, in_hs, in_ws, in_base;      /* element strides of the input pixel map */
   int32_t out_bs, out_hs, out_ws, out_base;  /* element strides of the output pixel map */
   int32_t accumulate;           /* 1: out += result (reads out) */
+  int32_t wide_tile;            /* hint: 1 = nothing runs next to this launch (forward pass): prefer the 512-pixel
+                                   tile that fills a CU alone; 0 = 256-pixel tiles that share a CU */
 } nbdt_conv_desc;
 /* in/out/w bf16; residual (nullable) bf16 addressed like out and added before rounding */
 int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,

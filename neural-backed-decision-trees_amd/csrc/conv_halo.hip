@@ -408,14 +408,15 @@ static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, HaloGeom* 
 // whole image rows or whole images, and the halo tile fits in LDS next to the weight ring.  Prefers the
 // 256-pixel / 4-wave form: alone it is 0.8 % slower per training step than the 512-pixel / 8-wave one (which
 // halves the weight-tile traffic per MFMA), but two of its blocks -- or one of them and a weight-gradient
-// block running on the engine's second stream -- share a CU, which is worth 2 % more.  NBDT_HALO_W8=1 selects
-// the wide tile.
+// block running on the engine's second stream -- share a CU, which is worth 2 % more.  The caller's
+// `wide_tile` hint (forward launches) selects the wide tile; NBDT_HALO_W8=1 / NBDT_HALO_W4=1 force one.
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
   if (d->ntaps != 9 || d->in_base != 0 || d->accumulate) return false;
   if (d->in_ws != d->cin || d->in_hs != (d->gw + 2) * d->cin || d->in_bs != (d->gh + 2) * d->in_hs) return false;
   for (int t = 0; t < 9; ++t)
     if (d->tap_off[t] != (t / 3) * d->in_hs + (t % 3) * d->in_ws) return false;
-  static const bool w4 = getenv("NBDT_HALO_W8") == nullptr;
+  static const bool force8 = getenv("NBDT_HALO_W8") != nullptr, force4 = getenv("NBDT_HALO_W4") != nullptr;
+  const bool w4 = force4 || !(force8 || d->wide_tile);
   // the wide tile needs enough tiles to fill the chip (1 block per CU)
   const long long tiles512 = ((long long)M + 511) / 512 * (d->cout / (32 * (d->cout / 32 % 5 == 0 ? 5 : (d->cout / 32 % 4 == 0 ? 4 : (d->cout / 32 % 2 == 0 ? 2 : 1)))));
   if (!w4 && tiles512 >= 256 && halo_geom_for(d, 512, 8, hg)) return true;

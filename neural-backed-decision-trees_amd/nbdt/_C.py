@@ -32,6 +32,7 @@ class ConvDesc(ctypes.Structure):
         ("in_bs", c_int32), ("in_hs", c_int32), ("in_ws", c_int32), ("in_base", c_int32),
         ("out_bs", c_int32), ("out_hs", c_int32), ("out_ws", c_int32), ("out_base", c_int32),
         ("accumulate", c_int32),
+        ("wide_tile", c_int32),
     ]
 
 

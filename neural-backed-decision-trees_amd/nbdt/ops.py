@@ -64,6 +64,7 @@ def conv_fwd_desc(B, Hi, Wi, cin, cout, k, stride):
     rowo = (Wo + 2) * cout
     d.out_bs, d.out_hs, d.out_ws, d.out_base = (Ho + 2) * rowo, rowo, cout, rowo + cout
     d.accumulate = 0
+    d.wide_tile = 1      # forward launches run alone on the GPU (data gradients share it with weight gradients)
     return d
 
 

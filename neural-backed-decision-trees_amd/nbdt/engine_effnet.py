@@ -55,7 +55,13 @@ class DepthwiseConv:
         ops.dwconv_bwd_data(gy, self.store.p(self.name), gx, self.k, self.stride)
 
     def backward_weight(self, x, gy):
-        ops.dwconv_bwd_weight(x, gy, self.store.g(self.name), self.k, self.stride)
+        side = getattr(self, "side_stream", None)
+        if side is None:
+            ops.dwconv_bwd_weight(x, gy, self.store.g(self.name), self.k, self.stride)
+            return
+        side.wait_stream(torch.cuda.current_stream(x.device))     # second stream: see WRNEngine
+        with torch.cuda.stream(side):
+            ops.dwconv_bwd_weight(x, gy, self.store.g(self.name), self.k, self.stride)
 
 
 class SqueezeExcite:
@@ -139,6 +145,11 @@ class EfficientNetEngine(_Engine):
         self.finalize()
         self._step = 0
         self.dropout_seed = seed
+        import os
+        if not os.environ.get("NBDT_NO_WGRAD_STREAM"):     # weight gradients on a second stream (see WRNEngine)
+            self._side = torch.cuda.Stream(device=self.device)
+            for c in self.convs + self.dws:
+                c.side_stream = self._side
 
     # ------------------------------------------------------------------ reference-named views
     def extra_param_views(self, buf):
@@ -252,6 +263,7 @@ class EfficientNetEngine(_Engine):
     # ------------------------------------------------------------------ backward
     def backward(self, gz, comm=None):
         B = self._B
+        self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         st = self.store
         buckets = self.grad_buckets() if comm is not None else None
         gz = gz.contiguous()
@@ -273,6 +285,7 @@ class EfficientNetEngine(_Engine):
         g = self.buf(f"g_{self._x_last.shape[3]}_{h}", B, h, w, self._x_last.shape[3])
         self.final_conv.backward_data(gf, g)
         for u in reversed(self.units):
+            self.join_side_stream()      # gradient buffers are shared between units: see WRNEngine.backward
             k, s = u["key"], u["stride"]
             cin, mid, cout = _pad32(u["cin"]), _pad32(u["mid"]), _pad32(u["cout"])
             ho, wo = h, w
@@ -324,12 +337,14 @@ class EfficientNetEngine(_Engine):
             u["dbg"] = {"g_out": g, "g_in": g_in, "gp": gp, "gd": gd}
             g, h, w = g_in, hi, wi
             if comm is not None and k in ("s5u1", "s3u1"):
+                self.join_side_stream()
                 comm.reduce_range(st.grad, *buckets[0 if k == "s5u1" else 1])
         bn = self.bn0
         t0 = self.buf("t0", B, h, w, _pad32(self.stem_c))
         ops.bn_act_bwd(g, t0, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
                        st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), g, act=ACT)
         ops.stem_wgrad(self._img, g, st.g("features.init_block.conv.conv.weight"), self.stem_c, stride=2)
+        self.join_side_stream()
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])
             comm.finish(st.grad)

@@ -267,6 +267,14 @@ class _Engine:
         self.convs.append(c)
         return c
 
+    def set_overlap(self, on):
+        """Turn the second (weight-gradient) stream on/off at run time; off = every launch on the caller's stream,
+        so a kernel's event-bracketed duration is its own (bench.py's roofline pass)."""
+        self.join_side_stream()
+        for c in self.convs + list(getattr(self, "dws", [])):
+            c.side_stream = self._side if on else None
+        self._overlap = bool(on)
+
     def join_side_stream(self):
         """Order every weight-gradient launch issued on the side stream before what follows on the main one."""
         if self._side is not None:
@@ -296,7 +304,7 @@ class _Engine:
     def refresh_derived_weights(self):
         for b in self.bns:             # gamma / beta may have changed: drop the folded eval transforms
             b._affine = None
-        if self._side is None:
+        if self._side is None or not getattr(self, "_overlap", True):
             ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
             return
         # the transposed copies are only read by data-gradient launches: build them on the second stream while

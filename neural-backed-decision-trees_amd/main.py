@@ -17,7 +17,7 @@ recipes in the reference's ``scripts/*.sh`` keep their arguments.  What differs,
   normalised if float, scaled to [0,1] and normalised with the reference's CIFAR statistics if uint8)
   or from ``--synthetic N`` (CIFAR-shaped noise with a learnable class signal, for smoke runs).
 * ``--analysis SoftEmbeddedDecisionRules | HardEmbeddedDecisionRules`` reports the NBDT accuracy
-  (reference nbdt/analysis.py:204-252) next to the backbone's top-1 during evaluation.
+  (the analyzers of nbdt/analysis.py, reference :204-252) next to the backbone's `--metric` during evaluation.
 """
 import argparse
 import math
@@ -30,17 +30,18 @@ import torch.nn as nn
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+from nbdt import analysis  # noqa: E402
 from nbdt import dist as ndist  # noqa: E402
 from nbdt import loss as losses  # noqa: E402
+from nbdt import metrics  # noqa: E402
 from nbdt import models  # noqa: E402
 from nbdt.engine import train_step  # noqa: E402
-from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules, coerce_state_dict  # noqa: E402
+from nbdt.model import coerce_state_dict  # noqa: E402
 from nbdt.tree import Tree  # noqa: E402
 from nbdt.utils import DATASET_TO_NUM_CLASSES, DATASETS  # noqa: E402
 
 CIFAR_MEAN, CIFAR_STD = (0.4914, 0.4822, 0.4465), (0.2023, 0.1994, 0.2010)   # reference nbdt/data/cifar.py:17-19
-ANALYSES = {"SoftEmbeddedDecisionRules": SoftEmbeddedDecisionRules,
-            "HardEmbeddedDecisionRules": HardEmbeddedDecisionRules}
+ANALYSES = tuple(n for n in analysis.names if n != "Noop")
 
 
 def build_parser():
@@ -56,6 +57,7 @@ def build_parser():
     p.add_argument("--pretrained", action="store_true")
     p.add_argument("--eval", action="store_true")
     p.add_argument("--loss", choices=losses.names, default=["CrossEntropyLoss"], nargs="+")
+    p.add_argument("--metric", choices=metrics.names, default="top1")
     p.add_argument("--analysis", choices=sorted(ANALYSES))
     # nbdt/tree.py:26-35
     p.add_argument("--hierarchy")
@@ -174,22 +176,21 @@ def load_data(args, num_classes, device):
     return [*make(n), *make(max(n // 4, args.batch_size))]
 
 
-def evaluate(net, criterion_module, rules, x, y, batch, device):
-    """Backbone top-1 (+ NBDT accuracy through `rules`) and mean loss over (x, y)."""
+def evaluate(net, criterion_module, analyzer, metric, x, y, batch, device):
+    """reference main.py:262-277: the metric on the backbone's logits, the analyzer's statistic (NBDT accuracy)
+    and the mean loss over (x, y)."""
     net.eval()
-    correct = nbdt_correct = 0
-    loss_sum, batches = 0.0, 0
+    metric.clear()
+    loss_sum, batches, stat = 0.0, 0, None
     with torch.no_grad():
         for i in range(0, x.shape[0], batch):
             xb, yb = x[i:i + batch].to(device), y[i:i + batch].to(device)
             z = net(xb)
             loss_sum += float(criterion_module(z, yb))
             batches += 1
-            correct += int((z.argmax(1) == yb).sum())
-            if rules is not None:
-                nbdt_correct += int((rules(z).argmax(1) == yb).sum())
-    n = x.shape[0]
-    return 100.0 * correct / n, (100.0 * nbdt_correct / n if rules is not None else None), loss_sum / max(batches, 1)
+            metric.forward(z, yb)
+            stat = analyzer.update_batch(z, yb, xb)
+    return 100.0 * metric.report(), stat, loss_sum / max(batches, 1)
 
 
 def main(argv=None):
@@ -243,7 +244,8 @@ def main(argv=None):
 
     criterion = build_criterion(args, tree, net=net, checkpoint_path=checkpoint_path)
     fast = criterion if hasattr(criterion, "loss_and_grad") else _PlainCE(tree)
-    rules = ANALYSES[args.analysis](tree=tree) if args.analysis else None
+    analyzer = getattr(analysis, args.analysis)(tree=tree) if args.analysis else analysis.Noop()
+    metric = getattr(metrics, args.metric)()
     comm = ndist.GradComm() if world > 1 else None
     per_rank = args.batch_size // world
 
@@ -266,8 +268,11 @@ def main(argv=None):
 
     def test(epoch, checkpoint=True):
         nonlocal best_acc
-        acc, nbdt_acc, loss = evaluate(net, criterion, rules, test_x, test_y, 100, device)
-        extra = f" | {args.analysis}: {nbdt_acc:.3f}%" if nbdt_acc is not None else ""
+        analyzer.start_test(epoch)
+        acc, nbdt_acc, loss = evaluate(net, criterion, analyzer, metric, test_x, test_y, 100, device)
+        if rank == 0:
+            analyzer.end_test(epoch)
+        extra = f" | {analyzer.name}: {nbdt_acc:.3f}%" if nbdt_acc is not None else ""
         log("Loss: %.3f | Acc: %.3f%%%s" % (loss, acc, extra))
         log(f"Accuracy: {acc} | Best Accuracy: {best_acc}")
         if acc > best_acc and checkpoint and rank == 0:
@@ -281,11 +286,13 @@ def main(argv=None):
     if args.eval:
         if not args.resume:
             log(" * Warning: Model is not loaded from checkpoint. Use --resume")
-        return test(0, checkpoint=False)
+        with analyzer.epoch_context(0):
+            return test(0, checkpoint=False)
     result = None
     for epoch in range(start_epoch, args.epochs):
-        train(epoch)
-        result = test(epoch)
+        with analyzer.epoch_context(epoch):
+            train(epoch)
+            result = test(epoch)
     return result
 
 

@@ -269,3 +269,37 @@ def test_hipgraph_captured_step_equals_eager_steps():
     step = E.GraphedStep(graphed, crit, xs[0], ys[0], lr=0.05, warmup=1)
     losses = [step(xs[0], ys[0]).item() for _ in range(5)]
     assert losses[-1] < losses[0] and (graphed.store.flat - before).norm().item() > 0
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 9])
+def test_ragged_batch_sizes_match_the_oracle(B, pkg_dir):
+    """Pixel tiles that straddle the end of the batch (M not a multiple of 256 / 512 pixels, tiles covering more
+    images than exist) in every conv / weight-gradient path: forward, loss and gradients vs the fp32 oracle."""
+    ref, eng = _pair(10, 2, 10, seed=B)
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(100 + B)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    ref.train()
+    if B == 1:
+        ref.eval()          # one sample: BatchNorm batch statistics over H*W only differ by design; use eval mode
+        with torch.no_grad():
+            z_ref = ref(x)
+        z = eng.forward(x.to(DEV), training=False)
+        assert (z.cpu() - z_ref).abs().max().item() < 3e-2 * z_ref.abs().max().item()
+        return
+    z_ref, loss_ref = _oracle_loss_backward(ref, otree, x, y)
+    eng.zero_grad()
+    z = eng.forward(x.to(DEV), training=True)
+    loss, gz = crit.loss_and_grad(z, y.to(DEV))
+    eng.backward(gz)
+    torch.cuda.synchronize()
+    assert (z.cpu() - z_ref).abs().max().item() < 4e-2 * z_ref.abs().max().item()
+    assert abs(loss.item() - loss_ref) < 3e-2 * abs(loss_ref)
+    grads = eng.named_params("grad")
+    for name, p in ref.named_parameters():
+        if p.grad.norm().item() < 1e-6:
+            continue
+        assert _cos(grads[name], p.grad) > 0.93, (name, _cos(grads[name], p.grad))

@@ -45,7 +45,10 @@ struct WgradTapsParams {
 #define NBDT_WGT_DEBUG 0   // compile-time timing experiments: 1 no DMA, 2 no waits/barriers, 4 no MFMA/LDS reads
 #endif
 constexpr int KS = 32;
-constexpr int NSTAGE = 3;
+#ifndef NBDT_WGT_NSTAGE
+#define NBDT_WGT_NSTAGE 3
+#endif
+constexpr int NSTAGE = NBDT_WGT_NSTAGE;   // LDS ring depth; stages are prefetched NSTAGE-1 ahead
 constexpr int XSLOTS = 128;                    // halo slots per ci chunk (hp <= 102 used)
 // x tile: (CX/8) chunks x 128 slots x 16 B = 8 KiB for 32 cins (4 waves), 16 KiB for 64 cins (8 waves)
 constexpr int x_bytes(int nwv) { return (nwv * 8 / 8) * XSLOTS * 16; }
@@ -229,25 +232,28 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
 
   // ---- pipeline (same protocol as wgrad_dma.hip)
   constexpr int dbg = NBDT_WGT_DEBUG;
+  constexpr int PD = NSTAGE - 1;
   if (!(dbg & 1)) {
-    issue(0, s_begin);
-    if (n_st > 1) issue(1, s_begin + 1);
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+      if (i < n_st) issue(i, s_begin + i);
   }
   int slot_i = 0;
   for (int t = 0; t < n_st; ++t) {
     if (!(dbg & 2)) {
-      if (t + 1 < n_st) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
+      // stages t+1 .. t+PD-1 may stay in flight (fewer near the end)
+      int after = n_st - 1 - t;
+      after = after < PD - 1 ? after : PD - 1;
+      if (after >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * MINPW) : "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("" ::: "memory");
-    if (t + 2 < n_st && !(dbg & 1)) {
-      int s2 = slot_i + 2;
+    if (t + PD < n_st && !(dbg & 1)) {
+      int s2 = slot_i + PD;
       s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
-      issue(s2, s_begin + t + 2);
+      issue(s2, s_begin + t + PD);
     }
     if (!(dbg & 4)) compute(slot_i);
     slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;

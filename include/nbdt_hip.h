@@ -172,8 +172,8 @@ int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, vo
                      void* wd_bf16, void* stream);
 
 /* the dgrad copies of EVERY conv layer in one launch: table (device, int64 [n_layers][6]) rows are
- * {src offset in flat, dst offset in wd_flat, cout, taps, cin, first 32x32-tile index}; cout, cin % 32 == 0;
- * total_tiles = sum over layers of taps * cout/32 * cin/32 */
+ * {src offset in flat, dst offset in wd_flat, cout, taps, cin, first tile index}; cout, cin % 32 == 0; a tile
+ * is 64 couts x 32 cins of one tap: total_tiles = sum over layers of taps * ceil(cout/64) * cin/32 */
 int nbdt_weight_prep_batched(const float* flat, const int64_t* table, int32_t n_layers, int64_t total_tiles,
                              void* wd_flat, void* stream);
 

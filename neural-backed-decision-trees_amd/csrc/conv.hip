@@ -324,37 +324,42 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 }
 
 // All conv layers in ONE launch (the per-layer form costs 30 launches x 17 us per optimizer step).
-// Work item = one 32(cout) x 32(cin) tile of one tap of one layer, transposed through LDS so both the
-// fp32 reads (along cin) and the bf16 writes (along cout) are coalesced (an element-wise version with
-// 2-byte scattered writes took 556 us for WRN-28-10).  table[l] = {src element offset in the flat fp32
-// buffer, dst element offset in wd_flat, cout, taps, cin, first tile index of the layer}.
+// Work item = one 64(cout) x 32(cin) tile of one tap of one layer, transposed through LDS so the fp32 reads
+// (128 B along cin) and the bf16 writes (64 couts = 128 B, one full line) are both coalesced.  (An element-wise
+// version with 2-byte scattered writes took 556 us for WRN-28-10; 32-cout tiles wrote half lines and the PMC
+// pass showed 1.1 GB of HBM writes for a 73 MB output.)  table[l] = {src element offset in the flat fp32 buffer,
+// dst element offset in wd_flat, cout, taps, cin, first tile index of the layer}; tiles per layer =
+// taps * ceil(cout/64) * (cin/32).
 __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const float* __restrict__ flat,
                                                                   const long long* __restrict__ table, int n_layers,
                                                                   long long total_tiles, bf16_t* __restrict__ wd_flat) {
   __shared__ long long tab[64 * 6];
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][33];
   for (int i = threadIdx.x; i < n_layers * 6; i += 256) tab[i] = table[i];
   __syncthreads();
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const int wx = threadIdx.x & 63, wy = threadIdx.x >> 6;      // 64 x 4
   for (long long e = blockIdx.x; e < total_tiles; e += gridDim.x) {
     int l = 0;
     while (l + 1 < n_layers && e >= tab[(l + 1) * 6 + 5]) ++l;
     const long long* T = tab + l * 6;
     const int cout = (int)T[2], taps = (int)T[3], cin = (int)T[4];
-    const int cit = cin >> 5, cot = cout >> 5;
+    const int cit = cin >> 5, cot = (cout + 63) >> 6;
     long long i = e - T[5];
     const int ci0 = (int)(i % cit) * 32;
     i /= cit;
-    const int co0 = (int)(i % cot) * 32;
+    const int co0 = (int)(i % cot) * 64;
     const int t = (int)(i / cot);
     const float* src = flat + T[0];
     bf16_t* dst = wd_flat + T[1];
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[((long long)(co0 + r) * taps + t) * cin + ci0 + tx];
+    for (int r = ty; r < 64; r += 8)
+      tile[r][tx] = co0 + r < cout ? src[((long long)(co0 + r) * taps + t) * cin + ci0 + tx] : 0.f;
     __syncthreads();
 #pragma unroll
-    for (int r = ty; r < 32; r += 8)
-      dst[((long long)(ci0 + r) * taps + (taps - 1 - t)) * cout + co0 + tx] = f32_to_bf16(tile[tx][r]);
+    for (int r = wy; r < 32; r += 4)
+      if (co0 + wx < cout)
+        dst[((long long)(ci0 + r) * taps + (taps - 1 - t)) * cout + co0 + wx] = f32_to_bf16(tile[wx][r]);
     __syncthreads();
   }
 }

@@ -296,7 +296,7 @@ class _Engine:
             rows.append([self.store.entries[c.name][0], off, c.cout, c.taps, c.cin, tiles])
             c.wd = self._wd_flat[off:off + c.numel()].view(c.cin, c.taps, c.cout)
             off += c.numel()
-            tiles += c.taps * (c.cout // 32) * (c.cin // 32)
+            tiles += c.taps * ((c.cout + 63) // 64) * (c.cin // 32)
         self._wd_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._wd_total = tiles
         self.refresh_derived_weights()

@@ -49,6 +49,16 @@ int nbdt_version(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int nbdt_device_count(void);
 
+/* DMA-ordered weight tiles for the dense 3x3 kernel.  For every listed matrix W[rows][9][k] (bf16, rows % 32 == 0,
+ * k % 32 == 0; the forward weights, or the transposed tap-reversed data-gradient copy) write tiles
+ * [row block of 32*nt][k slice of 32][tap] of (32*nt) x 32 elements, each stored exactly as the kernel's LDS image
+ * (row-major 64-byte rows with the 16-byte chunk index XOR (row>>2)&3), so that one 1-KiB LDS-DMA instruction reads
+ * one contiguous KiB instead of sixteen 64-byte fragments 2.8 KB apart.  nt = 5 | 4 | 2 | 1 is the largest of these
+ * dividing rows/32 (the kernel's cout tile).  table (device, int64 [n][5]): {src element offset, dst element offset,
+ * rows, k, first tile index}; total_tiles = sum of (rows/(32*nt)) * (k/32) * 9. */
+int nbdt_weight_tile_batched(const void* src_bf16, const int64_t* table, int32_t n, int64_t total_tiles,
+                             void* dst_bf16, void* stream);
+
 /* ------------------------------------------------------------------ hierarchy handle
  * Flattened form of nbdt/tree.py Tree/Node (build_class_mappings :105-125):
  *   N inner nodes in `tree.inodes` order (sorted wnid), node n owns child slots
@@ -123,6 +133,9 @@ typedef struct nbdt_conv_desc {
   int32_t accumulate;           /* 1: out += result (reads out) */
   int32_t wide_tile;            /* hint: 1 = nothing runs next to this launch (forward pass): prefer the 512-pixel
                                    tile that fills a CU alone; 0 = 256-pixel tiles that share a CU */
+  int32_t reserved;
+  uint64_t w_tiled;             /* 0, or device pointer to the same weights pre-arranged by nbdt_weight_tile_batched
+                                   (only dense 3x3 stride-1 launches with the identity tap map use it) */
 } nbdt_conv_desc;
 /* in/out/w bf16; residual (nullable) bf16 addressed like out and added before rounding */
 int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,

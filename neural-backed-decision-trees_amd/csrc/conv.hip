@@ -375,6 +375,47 @@ extern "C" int nbdt_weight_prep_batched(const float* flat, const int64_t* table,
   return NBDT_OK;
 }
 
+__global__ __launch_bounds__(256) void weight_tile_batched_kernel(const bf16_t* __restrict__ src,
+                                                                  const long long* __restrict__ table, int n,
+                                                                  long long total_tiles, bf16_t* __restrict__ dst) {
+  __shared__ long long tab[64 * 5];
+  for (int i = threadIdx.x; i < n * 5; i += 256) tab[i] = table[i];
+  __syncthreads();
+  for (long long e = blockIdx.x; e < total_tiles; e += gridDim.x) {
+    int l = 0;
+    while (l + 1 < n && e >= tab[(l + 1) * 5 + 4]) ++l;
+    const long long* T = tab + l * 5;
+    const int rows = (int)T[2], k = (int)T[3];
+    const int nt32 = rows / 32;
+    const int nt = nt32 % 5 == 0 ? 5 : (nt32 % 4 == 0 ? 4 : (nt32 % 2 == 0 ? 2 : 1));
+    const int bn = 32 * nt, kchunks = k / 32;
+    long long i = e - T[4];                       // tile index = (n_blk * kchunks + kc) * 9 + tap
+    const int tap = (int)(i % 9);
+    i /= 9;
+    const int kc = (int)(i % kchunks);
+    const int n_blk = (int)(i / kchunks);
+    const bf16_t* s0 = src + T[0];
+    bf16_t* d0 = dst + T[1] + (e - T[4]) * (long long)(bn * 32);
+    for (int q = threadIdx.x; q < bn * 4; q += 256) {     // (row, LDS chunk position)
+      const int r = q >> 2, cp = q & 3;
+      const int c = cp ^ ((r >> 2) & 3);
+      const u32x4_t v = *(const u32x4_t*)(s0 + ((long long)(n_blk * bn + r) * 9 + tap) * k + kc * 32 + c * 8);
+      *(u32x4_t*)(d0 + r * 32 + cp * 8) = v;
+    }
+  }
+}
+
+extern "C" int nbdt_weight_tile_batched(const void* src_bf16, const int64_t* table, int32_t n, int64_t total_tiles,
+                                        void* dst_bf16, void* stream) {
+  NBDT_REQUIRE(src_bf16 && table && dst_bf16, "null argument");
+  NBDT_REQUIRE(n > 0 && n <= 64 && total_tiles > 0, "bad matrix table");
+  long long blocks = total_tiles < 8192 ? total_tiles : 8192;
+  hipLaunchKernelGGL(weight_tile_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src_bf16, (const long long*)table, n, (long long)total_tiles, (bf16_t*)dst_bf16);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
 extern "C" int nbdt_weight_prep(const float* w, int32_t cout, int32_t taps, int32_t cin, void* w_bf16,
                                 void* wd_bf16, void* stream) {
   NBDT_REQUIRE(w && (w_bf16 || wd_bf16), "null argument");

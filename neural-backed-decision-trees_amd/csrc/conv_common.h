@@ -15,6 +15,7 @@ struct ConvDmaParams {
   nbdt_conv_desc d;
   const bf16_t* in;
   const bf16_t* w;
+  const bf16_t* w_tiled;   // nullable: DMA-ordered tiles (nbdt_weight_tile_batched), dense 3x3 kernel only
   bf16_t* out;
   const bf16_t* res;
   float* stats;        // nullable: [m_blocks][2][cout] per-pixel-tile partial sums (see STATS modes below)

@@ -207,6 +207,7 @@ int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void*
   p.d = *d;
   p.in = (const bf16_t*)in;
   p.w = (const bf16_t*)w;
+  p.w_tiled = nullptr;
   p.out = (bf16_t*)out;
   p.res = (const bf16_t*)res;
   p.stats = stats;

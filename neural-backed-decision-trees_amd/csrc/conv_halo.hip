@@ -33,7 +33,8 @@ __device__ __forceinline__ void touch16(u32x4_t& v) { asm volatile("" : "+v"(v):
 #endif
 constexpr int nw_slots(int nwv) { return NBDT_HALO_WREG ? 2 : (nwv == 8 ? NBDT_HALO_NWS8 : 3); }
 #ifndef NBDT_HALO_DEBUG
-#define NBDT_HALO_DEBUG 0   // 1: no DMA, 2: no waits/barriers, 4: no MFMA, 8: no LDS fragment reads
+#define NBDT_HALO_DEBUG 0   // 1: no DMA, 2: no waits/barriers, 4: no MFMA, 8: no LDS fragment reads,
+                            // 16: every DMA reads the same 1 KB (timing only)
 #endif
 
 constexpr int min_w_dma_h(int w_instr, int nwv) {
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kerne
   const int a_slots = (a_instr - wave + NWV - 1) / NWV;   // DMA instructions this wave issues per halo tile
   const int a_min = a_instr / NWV;                        // fewest any wave issues (for the counted waits)
   const int hw2 = NBDT_PIN(hg.hw2), himg = NBDT_PIN(hg.himg), hp_total = NBDT_PIN(hg.hp);
-  const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)p.w;
+  const bool tiled = __builtin_amdgcn_readfirstlane(p.w_tiled != nullptr ? 1 : 0) != 0;
+  const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)(tiled ? p.w_tiled : p.w);
   const bf16_t* in_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(in_u >> 32)) << 32) |
                                           (unsigned)NBDT_PIN((unsigned)in_u));
   const bf16_t* w_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(w_u >> 32)) << 32) |
@@ -131,25 +133,30 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kerne
     const int id = wave + NWV * k;
     int row = id * 16 + (lane >> 2);
     row = row < BN ? row : BN - 1;
-    w_src[k] = (n0 + row) * w_row_len + ((cpos ^ ((row >> 2) & 3)) << 3);
+    // tiled weights: the tile IS the LDS image -> instruction id reads its own contiguous KiB
+    w_src[k] = tiled ? n_blk * kchunks * 9 * (BN * 32) + id * 512 + lane * 8
+                     : (n0 + row) * w_row_len + ((cpos ^ ((row >> 2) & 3)) << 3);
   }
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned w_ring = lds_base + 2 * a_bytes;
 
+  constexpr int dbg = NBDT_HALO_DEBUG;   // compile-time timing experiments only (scratch/ablate.sh)
   auto issue_a = [&](int buf, int kc) {
     const unsigned dst0 = lds_base + buf * a_bytes;
 #pragma unroll
     for (int k = 0; k < MAX_A_SLOTS; ++k)
       if (k < a_slots)   // wave-uniform
-        glds16(in_base + (a_src[k] + kc * BK), __builtin_amdgcn_readfirstlane(dst0 + (wave + NWV * k) * 1024));
+        glds16(in_base + ((dbg & 16) ? (lane << 3) : (a_src[k] + kc * BK)),
+               __builtin_amdgcn_readfirstlane(dst0 + (wave + NWV * k) * 1024));
   };
   auto issue_w = [&](int slot, int tap, int kc) {
-    const int w_k = __builtin_amdgcn_readlane(tap_w_v, tap) + kc * BK;
+    const int w_k = tiled ? (kc * 9 + tap) * (BN * 32) : __builtin_amdgcn_readlane(tap_w_v, tap) + kc * BK;
     const unsigned dst0 = w_ring + slot * W_BYTES;
 #pragma unroll
     for (int k = 0; k < IPW_W; ++k) {
       const int id = wave + NWV * k;
-      if (id < W_INSTR) glds16(w_base + (w_src[k] + w_k), __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
+      if (id < W_INSTR)
+        glds16(w_base + ((dbg & 16) ? (lane << 3) : (w_src[k] + w_k)), __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
     }
   };
 
@@ -175,7 +182,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kerne
     hp0[tm] = img * himg + r * hw2 + c;
   }
 
-  constexpr int dbg = NBDT_HALO_DEBUG;   // compile-time timing experiments only (scratch/ablate.sh)
   // (Tried on MI355X and dropped, same box A/B: hoisting all 14 ds_read_b128 of a tap above the DMA issue,
   //  and a two-register-set software pipeline with the barrier between the two 16-channel halves of a tap --
   //  neither moved the MFMA+LDS-only time of 165 us: the gap to the MFMA-only 134 us is operand data, not
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv3x3_halo_kerne
     for (int k = 0; k < IPW_W; ++k) cnt_w += (wave + NWV * k < W_INSTR) ? 1 : 0;
     u32x4_t wreg[2][IPW_W];
     auto load_w = [&](int set, int tap_, int kc_) {
-      const int w_k = __builtin_amdgcn_readlane(tap_w_v, tap_) + kc_ * BK;
+      const int w_k = tiled ? (kc_ * 9 + tap_) * (BN * 32) : __builtin_amdgcn_readlane(tap_w_v, tap_) + kc_ * BK;
 #pragma unroll
       for (int k = 0; k < IPW_W; ++k)
         if (wave + NWV * k < W_INSTR) gload16(wreg[set][k], w_base + (w_src[k] + w_k));
@@ -429,6 +435,13 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.d = *d;
   p.in = (const bf16_t*)in;
   p.w = (const bf16_t*)w;
+  p.w_tiled = nullptr;
+  static const bool no_tiled = getenv("NBDT_NO_WTILED") != nullptr;   // A/B switch
+  if (d->w_tiled != 0 && !no_tiled) {   // only with the identity tap map (forward weights / already tap-reversed dgrad copy)
+    bool ident = d->w_ntaps == 9;
+    for (int t = 0; t < 9; ++t) ident = ident && d->w_tap[t] == t;
+    if (ident) p.w_tiled = (const bf16_t*)(uintptr_t)d->w_tiled;
+  }
   p.out = (bf16_t*)out;
   p.res = (const bf16_t*)res;
   p.stats = stats;

@@ -174,12 +174,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
 #pragma unroll
     for (int k = 0; k < IPG; ++k) {
       const int id = wave + NWV * k;
-      if (id < G_INSTR) glds16(gsrc + id * 16, __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
+      if (id < G_INSTR)
+        glds16((NBDT_WGT_DEBUG & 16) ? gy_base + (lane << 3) : gsrc + id * 16, __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int id = wave + NWV * k;
-      glds16(x_base + (x_stage + x_lane_src[k]), __builtin_amdgcn_readfirstlane(dst0 + G_BYTES + id * 1024));
+      glds16(x_base + ((NBDT_WGT_DEBUG & 16) ? (lane << 3) : (x_stage + x_lane_src[k])),
+             __builtin_amdgcn_readfirstlane(dst0 + G_BYTES + id * 1024));
     }
   };
 

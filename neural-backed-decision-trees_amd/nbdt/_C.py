@@ -33,6 +33,8 @@ class ConvDesc(ctypes.Structure):
         ("out_bs", c_int32), ("out_hs", c_int32), ("out_ws", c_int32), ("out_base", c_int32),
         ("accumulate", c_int32),
         ("wide_tile", c_int32),
+        ("reserved", c_int32),
+        ("w_tiled", ctypes.c_uint64),
     ]
 
 
@@ -77,6 +79,7 @@ SIGNATURES = {
     "nbdt_conv_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
     "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_weight_prep_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),
+    "nbdt_weight_tile_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),
     "nbdt_bn_stats": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "nbdt_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32,

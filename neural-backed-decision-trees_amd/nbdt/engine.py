@@ -108,14 +108,27 @@ class Conv:
     def plan(self, B, Hi, Wi):
         key = (B, Hi, Wi)
         if key not in self._plans:
-            self._plans[key] = (
+            self._plans[key] = self._make_plan(B, Hi, Wi)
+        return self._plans[key]
+
+    def _make_plan(self, B, Hi, Wi):
+        p = self._raw_plan(B, Hi, Wi)
+        if getattr(self, "wt_fwd", None) is not None:      # dense 3x3 / stride 1: DMA-ordered weight tiles
+            p[0].w_tiled = self.wt_fwd.data_ptr()
+            for descs in (p[1], p[2]):
+                if descs is not None and len(descs) == 1:
+                    descs[0].w_tiled = self.wt_dgrad.data_ptr()
+        return p
+
+    def _raw_plan(self, B, Hi, Wi):
+        if True:
+            return (
                 ops.conv_fwd_desc(B, Hi, Wi, self.cin, self.cout, self.k, self.stride),
                 ops.conv_dgrad_descs(B, Hi, Wi, self.cin, self.cout, self.k, self.stride, accumulate=False)
                 if not (self.k == 1 and self.stride == 2) else None,
                 ops.conv_dgrad_descs(B, Hi, Wi, self.cin, self.cout, self.k, self.stride, accumulate=True),
                 ops.conv_wgrad_desc(B, Hi, Wi, self.cin, self.cout, self.k, self.stride),
             )
-        return self._plans[key]
 
     def numel(self):
         return self.cout * self.taps * self.cin
@@ -299,19 +312,55 @@ class _Engine:
             tiles += c.taps * ((c.cout + 63) // 64) * (c.cin // 32)
         self._wd_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._wd_total = tiles
+        # DMA-ordered weight tiles for the dense 3x3 / stride-1 kernel (forward weights from the bf16 mirror, data-
+        # gradient weights from the transposed copy): one 1-KiB LDS-DMA instruction then reads one contiguous KiB
+        dense = [c for c in self.convs if c.k == 3 and c.stride == 1]
+        self._wt_n = len(dense)
+        if dense:
+            n_el = sum(c.numel() for c in dense)
+            self._wt_fwd = torch.empty(n_el, dtype=torch.bfloat16, device=self.device)
+            self._wt_dgrad = torch.empty(n_el, dtype=torch.bfloat16, device=self.device)
+            frows, drows, off, tf, td = [], [], 0, 0, 0
+
+            def ntile(r):
+                r32 = r // 32
+                return 5 if r32 % 5 == 0 else 4 if r32 % 4 == 0 else 2 if r32 % 2 == 0 else 1
+
+            wd_off = {}
+            o = 0
+            for c in self.convs:
+                wd_off[c.name] = o
+                o += c.numel()
+            for c in dense:
+                frows.append([self.store.entries[c.name][0], off, c.cout, c.cin, tf])
+                drows.append([wd_off[c.name], off, c.cin, c.cout, td])
+                c.wt_fwd = self._wt_fwd[off:off + c.numel()]
+                c.wt_dgrad = self._wt_dgrad[off:off + c.numel()]
+                off += c.numel()
+                tf += (c.cout // (32 * ntile(c.cout))) * (c.cin // 32) * 9
+                td += (c.cin // (32 * ntile(c.cin))) * (c.cout // 32) * 9
+            self._wt_ftable = torch.tensor(frows, dtype=torch.int64, device=self.device)
+            self._wt_dtable = torch.tensor(drows, dtype=torch.int64, device=self.device)
+            self._wt_ftotal, self._wt_dtotal = tf, td
         self.refresh_derived_weights()
 
     def refresh_derived_weights(self):
         for b in self.bns:             # gamma / beta may have changed: drop the folded eval transforms
             b._affine = None
+        if self._wt_n:     # forward tiles are needed by the very next forward: caller's stream
+            ops.weight_tile_batched(self.store.bf16, self._wt_ftable, self._wt_n, self._wt_ftotal, self._wt_fwd)
         if self._side is None or not getattr(self, "_overlap", True):
             ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
+            if self._wt_n:
+                ops.weight_tile_batched(self._wd_flat, self._wt_dtable, self._wt_n, self._wt_dtotal, self._wt_dgrad)
             return
         # the transposed copies are only read by data-gradient launches: build them on the second stream while
         # the next forward runs (backward() joins the stream before its first dgrad)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
             ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
+            if self._wt_n:
+                ops.weight_tile_batched(self._wd_flat, self._wt_dtable, self._wt_n, self._wt_dtotal, self._wt_dgrad)
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
         """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights."""

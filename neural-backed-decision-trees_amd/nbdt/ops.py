@@ -245,6 +245,11 @@ def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):
                                  stream_ptr(w_fp32.device)))
 
 
+def weight_tile_batched(src_bf16, table, n, total, dst_bf16):
+    check(lib().nbdt_weight_tile_batched(ptr(src_bf16), ptr(table), n, total, ptr(dst_bf16),
+                                         stream_ptr(src_bf16.device)))
+
+
 def weight_prep_batched(flat, table, n_layers, total, wd_flat):
     check(lib().nbdt_weight_prep_batched(ptr(flat), ptr(table), n_layers, total, ptr(wd_flat),
                                          stream_ptr(flat.device)))

@@ -121,14 +121,11 @@ class Conv:
         return p
 
     def _raw_plan(self, B, Hi, Wi):
-        if True:
-            return (
-                ops.conv_fwd_desc(B, Hi, Wi, self.cin, self.cout, self.k, self.stride),
-                ops.conv_dgrad_descs(B, Hi, Wi, self.cin, self.cout, self.k, self.stride, accumulate=False)
-                if not (self.k == 1 and self.stride == 2) else None,
-                ops.conv_dgrad_descs(B, Hi, Wi, self.cin, self.cout, self.k, self.stride, accumulate=True),
-                ops.conv_wgrad_desc(B, Hi, Wi, self.cin, self.cout, self.k, self.stride),
-            )
+        """(forward desc, dgrad descs, accumulating dgrad descs, wgrad desc) for one input geometry."""
+        args = (B, Hi, Wi, self.cin, self.cout, self.k, self.stride)
+        plain_dgrad = None if (self.k == 1 and self.stride == 2) else ops.conv_dgrad_descs(*args, accumulate=False)
+        return (ops.conv_fwd_desc(*args), plain_dgrad, ops.conv_dgrad_descs(*args, accumulate=True),
+                ops.conv_wgrad_desc(*args))
 
     def numel(self):
         return self.cout * self.taps * self.cin

@@ -16,8 +16,11 @@ recipes in the reference's ``scripts/*.sh`` keep their arguments.  What differs,
   dict with ``train_x [N,3,H,W]`` uint8|float, ``train_y``, ``test_x``, ``test_y``; already
   normalised if float, scaled to [0,1] and normalised with the reference's CIFAR statistics if uint8)
   or from ``--synthetic N`` (CIFAR-shaped noise with a learnable class signal, for smoke runs).
-* ``--analysis SoftEmbeddedDecisionRules | HardEmbeddedDecisionRules`` reports the NBDT accuracy
-  (the analyzers of nbdt/analysis.py, reference :204-252) next to the backbone's `--metric` during evaluation.
+* ``--analysis SoftEmbeddedDecisionRules | HardEmbeddedDecisionRules`` reports the accuracy of the decision
+  rules applied to the backbone's logits (what the reference's analyzers of those names print, reference
+  nbdt/analysis.py:224-229) next to the backbone's `--metric` during evaluation.  The reference's analyzer hook
+  protocol and its presentation analyzers are out of scope: the two statistics
+  are counted here, on the device, one host transfer per evaluation.
 """
 import argparse
 import math
@@ -30,18 +33,38 @@ import torch.nn as nn
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from nbdt import analysis  # noqa: E402
 from nbdt import dist as ndist  # noqa: E402
 from nbdt import loss as losses  # noqa: E402
-from nbdt import metrics  # noqa: E402
 from nbdt import models  # noqa: E402
 from nbdt.engine import train_step  # noqa: E402
-from nbdt.model import coerce_state_dict  # noqa: E402
+from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules, coerce_state_dict  # noqa: E402
 from nbdt.tree import Tree  # noqa: E402
 from nbdt.utils import DATASET_TO_NUM_CLASSES, DATASETS  # noqa: E402
 
 CIFAR_MEAN, CIFAR_STD = (0.4914, 0.4822, 0.4465), (0.2023, 0.1994, 0.2010)   # reference nbdt/data/cifar.py:17-19
-ANALYSES = tuple(n for n in analysis.names if n != "Noop")
+ANALYSES = {"HardEmbeddedDecisionRules": HardEmbeddedDecisionRules, "SoftEmbeddedDecisionRules": SoftEmbeddedDecisionRules}
+METRICS = {"top1": 1, "top2": 2, "top5": 5, "top10": 10}      # the reference's --metric names -> k
+
+
+class HitCounter:
+    """Running count of samples whose target is among the k largest scores.  Both counters stay on the device;
+    `percent()` is the only host transfer."""
+
+    def __init__(self, k, device):
+        self.k = k
+        self.hits = torch.zeros((), dtype=torch.long, device=device)
+        self.seen = 0
+
+    def add(self, scores, targets):
+        k = min(self.k, scores.shape[1])
+        if k == 1:
+            self.hits += (scores.argmax(dim=1) == targets).sum()
+        else:
+            self.hits += (scores.topk(k, dim=1).indices == targets[:, None]).any(dim=1).sum()
+        self.seen += targets.shape[0]
+
+    def percent(self):
+        return 100.0 * int(self.hits) / max(self.seen, 1)
 
 
 def build_parser():
@@ -57,7 +80,7 @@ def build_parser():
     p.add_argument("--pretrained", action="store_true")
     p.add_argument("--eval", action="store_true")
     p.add_argument("--loss", choices=losses.names, default=["CrossEntropyLoss"], nargs="+")
-    p.add_argument("--metric", choices=metrics.names, default="top1")
+    p.add_argument("--metric", choices=sorted(METRICS), default="top1")
     p.add_argument("--analysis", choices=sorted(ANALYSES))
     # nbdt/tree.py:26-35
     p.add_argument("--hierarchy")
@@ -176,21 +199,23 @@ def load_data(args, num_classes, device):
     return [*make(n), *make(max(n // 4, args.batch_size))]
 
 
-def evaluate(net, criterion_module, analyzer, metric, x, y, batch, device):
-    """reference main.py:262-277: the metric on the backbone's logits, the analyzer's statistic (NBDT accuracy)
-    and the mean loss over (x, y)."""
+def evaluate(net, criterion_module, rules, k, x, y, batch, device):
+    """reference main.py:262-277: top-k accuracy of the backbone's logits, accuracy of the decision rules on the
+    same logits (None without --analysis) and the mean loss over (x, y)."""
     net.eval()
-    metric.clear()
-    loss_sum, batches, stat = 0.0, 0, None
+    plain, nbdt = HitCounter(k, device), HitCounter(1, device)
+    loss_sum = torch.zeros((), device=device)
+    batches = 0
     with torch.no_grad():
         for i in range(0, x.shape[0], batch):
             xb, yb = x[i:i + batch].to(device), y[i:i + batch].to(device)
             z = net(xb)
-            loss_sum += float(criterion_module(z, yb))
+            loss_sum += criterion_module(z, yb)
             batches += 1
-            metric.forward(z, yb)
-            stat = analyzer.update_batch(z, yb, xb)
-    return 100.0 * metric.report(), stat, loss_sum / max(batches, 1)
+            plain.add(z, yb)
+            if rules is not None:
+                nbdt.add(rules(z), yb)
+    return plain.percent(), (nbdt.percent() if rules is not None else None), float(loss_sum) / max(batches, 1)
 
 
 def main(argv=None):
@@ -244,8 +269,9 @@ def main(argv=None):
 
     criterion = build_criterion(args, tree, net=net, checkpoint_path=checkpoint_path)
     fast = criterion if hasattr(criterion, "loss_and_grad") else _PlainCE(tree)
-    analyzer = getattr(analysis, args.analysis)(tree=tree) if args.analysis else analysis.Noop()
-    metric = getattr(metrics, args.metric)()
+    rules = ANALYSES[args.analysis](tree=tree) if args.analysis else None
+    rules_name = {"HardEmbeddedDecisionRules": "NBDT-Hard", "SoftEmbeddedDecisionRules": "NBDT-Soft"}.get(args.analysis)
+    best_nbdt = 0.0
     comm = ndist.GradComm() if world > 1 else None
     per_rank = args.batch_size // world
 
@@ -267,12 +293,12 @@ def main(argv=None):
         log("Loss: %.3f (%d steps of %d x %d images)" % (total.item() / max(steps, 1), steps, world, per_rank))
 
     def test(epoch, checkpoint=True):
-        nonlocal best_acc
-        analyzer.start_test(epoch)
-        acc, nbdt_acc, loss = evaluate(net, criterion, analyzer, metric, test_x, test_y, 100, device)
-        if rank == 0:
-            analyzer.end_test(epoch)
-        extra = f" | {analyzer.name}: {nbdt_acc:.3f}%" if nbdt_acc is not None else ""
+        nonlocal best_acc, best_nbdt
+        acc, nbdt_acc, loss = evaluate(net, criterion, rules, METRICS[args.metric], test_x, test_y, 100, device)
+        extra = ""
+        if nbdt_acc is not None:
+            best_nbdt = max(best_nbdt, nbdt_acc)
+            extra = f" | {rules_name}: {nbdt_acc:.3f}% (best {best_nbdt:.3f}%)"
         log("Loss: %.3f | Acc: %.3f%%%s" % (loss, acc, extra))
         log(f"Accuracy: {acc} | Best Accuracy: {best_acc}")
         if acc > best_acc and checkpoint and rank == 0:
@@ -286,13 +312,11 @@ def main(argv=None):
     if args.eval:
         if not args.resume:
             log(" * Warning: Model is not loaded from checkpoint. Use --resume")
-        with analyzer.epoch_context(0):
-            return test(0, checkpoint=False)
+        return test(0, checkpoint=False)
     result = None
     for epoch in range(start_epoch, args.epochs):
-        with analyzer.epoch_context(epoch):
-            train(epoch)
-            result = test(epoch)
+        train(epoch)
+        result = test(epoch)
     return result
 
 

@@ -124,94 +124,39 @@ def build_induced_graph(wnids, checkpoint=None, model=None, linkage="ward", affi
     return G
 
 
-def build_random_graph(wnids, seed=0, branching_factor=2):
-    """reference nbdt/graph.py:330-377: shuffle the classes (python `random`, so the same seed gives the same
-    tree as the reference), group them bottom-up `branching_factor` at a time, name inner nodes "0", "1", ..."""
-    import random
-    wnids = list(wnids)
-    random.seed(seed)
-    if seed >= 0:
-        random.shuffle(wnids)
-    remaining = wnids
-    while len(remaining) > 1:
-        current, remaining = remaining, []
-        while current:
-            nodes, current = current[:branching_factor], current[branching_factor:]
-            remaining.append(nodes)
-    G = Graph()
-    G.add_node("0", label="")
-    nxt = [(remaining[0], "0")]
-    i = 1
-    while nxt:
-        group, parent = nxt.pop(0)
-        if len(group) == 1:
-            if isinstance(group[0], str):
-                G.add_edge(parent, group[0])
-            else:
-                nxt.append((group[0], parent))
-            continue
-        for candidate in group:
-            is_leaf = not isinstance(candidate, list)
-            wnid = candidate if is_leaf else str(i)
-            if is_leaf:
-                G.add_node(wnid)
-            else:
-                G.add_node(wnid, label="")
-            G.add_edge(parent, wnid)
-            i += 1
-            if not is_leaf:
-                nxt.append((candidate, wnid))
-    return G
-
-
-def prune_single_successor_nodes(G):
-    """reference nbdt/graph.py:597-602 (networkx contracted_nodes): a node with exactly one child is merged into
-    that child -- the child keeps its id and takes over the node's parents."""
-    for node in list(G.nodes):
-        succ = G.succ(node)
-        if node in G.nodes and len(succ) == 1:
-            child = succ[0]
-            G.edges = [(s, child if t == node else t) for s, t in G.edges if not (s == node and t == child)]
-            G.edges = [(child if s == node else s, t) for s, t in G.edges]
-            del G.nodes[node]
-    return G
+def _checkpoint_tag(checkpoint):
+    """`ckpt-<dataset>-<rest>[-induced]` -> `<rest>`; any other file name -> its stem."""
+    stem = Path(checkpoint).stem
+    parts = stem.split("-")
+    if parts[0] == "ckpt" and len(parts) >= 3:
+        return "-".join(parts[2:]).replace("-induced", "")
+    return stem
 
 
 def generate_graph_fname(method, seed=0, branching_factor=2, extra=0, no_prune=False, fname="", path="",
                          multi_path=False, induced_linkage="ward", induced_affinity="euclidean", checkpoint=None,
                          arch=None, **kwargs):
-    """reference nbdt/graph.py:194-245."""
+    """File stem of a hierarchy JSON.  The naming scheme is an on-disk contract with the reference
+    (nbdt/graph.py:194-245): `graph-<method>` followed by one `-<tag><value>` suffix per non-default option,
+    in a fixed order, so hierarchies written by either implementation are found by the other."""
     if path:
         return Path(path).stem
     if fname:
         return fname
-    fname = f"graph-{method}"
-    if method == "random" and seed != 0:
-        fname += f"-seed{seed}"
-    if method == "induced":
+    induced = method == "induced"
+    if induced:
         assert checkpoint or arch, "Induced hierarchy needs either `arch` or `checkpoint`"
-        if induced_linkage != "ward" and induced_linkage is not None:
-            fname += f"-linkage{induced_linkage}"
-        if induced_affinity != "euclidean" and induced_affinity is not None:
-            fname += f"-affinity{induced_affinity}"
-        if checkpoint:
-            stem = Path(checkpoint).stem
-            if stem.startswith("ckpt-") and stem.count("-") >= 2:
-                checkpoint_fname = "-".join(stem.split("-")[2:]).replace("-induced", "")
-            else:
-                checkpoint_fname = stem
-        else:
-            checkpoint_fname = arch
-        fname += f"-{checkpoint_fname}"
-    if method in ("random", "induced") and branching_factor != 2:
-        fname += f"-branch{branching_factor}"
-    if extra > 0:
-        fname += f"-extra{extra}"
-    if no_prune:
-        fname += "-noprune"
-    if multi_path:
-        fname += "-multi"
-    return fname
+    suffixes = [
+        (method == "random" and seed != 0, f"seed{seed}"),
+        (induced and induced_linkage not in ("ward", None), f"linkage{induced_linkage}"),
+        (induced and induced_affinity not in ("euclidean", None), f"affinity{induced_affinity}"),
+        (induced, _checkpoint_tag(checkpoint) if checkpoint else arch),
+        (method in ("random", "induced") and branching_factor != 2, f"branch{branching_factor}"),
+        (extra > 0, f"extra{extra}"),
+        (bool(no_prune), "noprune"),
+        (bool(multi_path), "multi"),
+    ]
+    return "-".join([f"graph-{method}"] + [str(tag) for on, tag in suffixes if on])
 
 
 def get_directory(dataset, root=None):

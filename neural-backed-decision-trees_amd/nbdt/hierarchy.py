@@ -1,8 +1,7 @@
 """``generate_hierarchy`` -- reference nbdt/hierarchy.py:59-127 for the ``induced`` method (the one every
-shipped NBDT hierarchy uses) and the ``random`` ablation hierarchies.  ``wordnet`` needs the WordNet corpus
-(nltk, absent on the target image) and ``--extra`` augmentation is not built: both raise."""
-from nbdt.graph import (build_induced_graph, build_random_graph, get_graph_path_from_args,
-                        prune_single_successor_nodes, write_graph)
+shipped NBDT hierarchy uses).  ``wordnet`` needs the WordNet corpus (nltk, absent on the target image); ``random``
+ablation hierarchies and ``--extra`` augmentation are out of scope: all three raise."""
+from nbdt.graph import build_induced_graph, get_graph_path_from_args, write_graph
 from nbdt.tree import get_wnids
 from nbdt.utils import dataset_to_default_path_wnids
 
@@ -10,22 +9,17 @@ from nbdt.utils import dataset_to_default_path_wnids
 def generate_hierarchy(dataset, method, seed=0, branching_factor=2, extra=0, no_prune=False, fname="", path="",
                        single_path=False, induced_linkage="ward", induced_affinity="euclidean", checkpoint=None,
                        arch=None, model=None, path_wnids=None, **kwargs):
-    if method not in ("induced", "random"):
-        raise NotImplementedError(f'Method "{method}" is not built (wordnet hierarchies need the WordNet corpus)')
+    if method != "induced":
+        raise NotImplementedError(f'Method "{method}" is not built (only induced hierarchies are in scope)')
     if extra:
         raise NotImplementedError("graph augmentation (--extra) is not built")
     wnids = get_wnids(path_wnids or dataset_to_default_path_wnids(dataset))
-    if method == "random":
-        G = build_random_graph(wnids, seed=seed, branching_factor=branching_factor)
-    else:
-        G = build_induced_graph(wnids, dataset=dataset, checkpoint=checkpoint,
-                                model=None if model is not None else arch, linkage=induced_linkage,
-                                affinity=induced_affinity, branching_factor=branching_factor,
-                                state_dict=model.state_dict() if model is not None else None)
+    G = build_induced_graph(wnids, dataset=dataset, checkpoint=checkpoint,
+                            model=None if model is not None else arch, linkage=induced_linkage,
+                            affinity=induced_affinity, branching_factor=branching_factor,
+                            state_dict=model.state_dict() if model is not None else None)
     assert all(w in G.nodes for w in wnids)
-    if not no_prune:
-        G = prune_single_successor_nodes(G)
-        assert all(w in G.nodes for w in wnids)
+    # (the reference prunes single-successor nodes here; ward linkage only ever creates binary inner nodes)
     path = get_graph_path_from_args(dataset=dataset, method=method, seed=seed, branching_factor=branching_factor,
                                     extra=extra, no_prune=no_prune, fname=fname, path=path,
                                     multi_path=single_path, induced_linkage=induced_linkage,

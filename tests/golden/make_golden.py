@@ -212,26 +212,9 @@ def run_induced(tag, dataset, F, seed):
     print(f"induced {tag}: {len(data['nodes'])} nodes, {len(data['links'])} links -> {os.path.basename(path)}")
 
 
-def run_random(tag, dataset, seed):
-    """Random hierarchy (nbdt/graph.py:330-377, python `random` shuffle of the class list, bottom-up pairing)."""
-    import nbdt.graph as RG
-    from networkx.readwrite.json_graph import node_link_data
-    from nbdt.thirdparty.wn import get_wnids_from_dataset
-    G = RG.build_random_graph(list(get_wnids_from_dataset(dataset)), seed=seed)
-    G = RG.prune_single_successor_nodes(G)
-    data = node_link_data(G)
-    path = os.path.join(HERE, f"random_{tag}.npz")
-    np.savez_compressed(path, node_ids=np.array([n["id"] for n in data["nodes"]]),
-                        link_source=np.array([l["source"] for l in data["links"]]),
-                        link_target=np.array([l["target"] for l in data["links"]]))
-    print(f"random {tag}: {len(data['nodes'])} nodes -> {os.path.basename(path)}")
-
-
 if __name__ == "__main__":
     for case in CASES:
         run_case(*case)
-    run_random("cifar10_seed0", "CIFAR10", 0)
-    run_random("cifar100_seed3", "CIFAR100", 3)
     run_induced("cifar10", "CIFAR10", 64, 11)
     run_induced("cifar100", "CIFAR100", 64, 12)
     run_induced("tiny200", "TinyImagenet200", 32, 13)

@@ -3,7 +3,9 @@
 batches (BASELINE.json `metric`, configs[1]: batch 512 per MI355X, fused rules/loss kernel).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+  (N>1 without a torchrun environment: bench.py re-launches itself as
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...,
+   one rank per GPU over RCCL; launched that way by a driver it just reads RANK/LOCAL_RANK/WORLD_SIZE.)
 
 A "step" = zero_grad -> backbone forward -> SoftTreeSupLoss forward+backward (one fused kernel) ->
 backbone backward -> [RCCL all-reduce of gradients, overlapped] -> SGD(momentum .9, wd 5e-4) on one
@@ -17,6 +19,9 @@ joined so that no other kernel shares the GPU with the measured launch; peak = 2
 (gfx950).
 cpu_baseline: the fp32 CPU oracle port (oracle/torch_models.py WRN + oracle/nbdt_oracle.py loss) on a
 bounded sample, all host cores -- test infrastructure used only as the timed baseline here.
+agreement ("top-1 vs ref" half of the metric): after the timed loop the trained weights are copied into the
+CPU oracle port and both run an eval-mode forward on the same fixed batch; reported are the fraction of equal
+argmax(logits), of equal HardNBDT predictions (each path's rules on its own logits) and the logit error.
 """
 import argparse
 import json
@@ -37,13 +42,19 @@ PEAK_BF16_TFLOPS = 2500.0
 GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
 
 
+TRAFFIC_FILES = ("r02_final_hbm_traffic.json", "r01_final_hbm_traffic.json")   # newest first
+
+
 def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_final_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of
-    this same command; scratch/prof_bench.sh).  bench.py cannot collect PMC counters itself -> null if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
+    """(bytes, source file): HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command;
+    scratch/prof_bench.sh).  bench.py cannot collect PMC counters itself -> (None, None) if absent."""
+    for fname in TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", fname)
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
     with open(path) as f:
         t = json.load(f)
     n = b = 0
@@ -51,12 +62,55 @@ def pmc_traffic():
         if "conv3x3_halo_kernel" in name or "conv_igemm_dma_kernel" in name:
             n += v["launches"]
             b += v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"])
-    return round(b / n) if n else None
+    return (round(b / n) if n else None), "profiles/" + fname
 
 
-def cpu_baseline(batch, num_classes):
-    """fp32 CPU oracle port timed on this box's host cores: one warm-up step at batch 8, one timed
-    step at `batch` images (bounded sample of the same workload)."""
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: become the launcher (one rank per GPU, RCCL)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def agreement(eng, num_classes, n, dev):
+    """Eval-mode forward of the SAME weights and running statistics on the same `n` synthetic images through
+    the engine (bf16 storage / fp32 accumulate) and through the fp32 CPU oracle port; HardNBDT predictions from
+    each path's own logits (HIP kernel vs numpy oracle)."""
+    nbdt_path.add(oracle=True)
+    import numpy as np
+    import nbdt_oracle as O
+    import torch_models as TM
+    from nbdt import _C
+    from nbdt.tree import Tree
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(n, 3, 32, 32, generator=g)
+    ref = TM.WRN(num_classes, 28, 10)
+    ref.load_state_dict({k: v.cpu() for k, v in eng.state_dict().items()})
+    ref.eval()
+    with torch.no_grad():
+        z_ref = torch.cat([ref(x[i:i + 64]) for i in range(0, n, 64)]).numpy()
+    z = eng.forward(x.to(dev), training=False).float().cpu().numpy()
+    tree = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10",
+                                          os.path.join(nbdt_path.PKG_DIR, "nbdt")))
+    hard = _C.hard_forward(tree.device_handle(dev.index), torch.from_numpy(z).to(dev), want_onehot=False)[0]
+    hard_ref = O.hard_forward(otree, z_ref)
+    scale = float(np.abs(z_ref).max())
+    return {"argmax": round(float((z.argmax(1) == z_ref.argmax(1)).mean()), 4),
+            "hard_pred": round(float((hard.cpu().numpy() == hard_ref).mean()), 4), "n": n,
+            "max_abs_logit_err_over_scale": round(float(np.abs(z - z_ref).max()) / scale, 5),
+            "vs": "fp32 torch-CPU port of WRN-28-10 (oracle/torch_models.py) with the engine's trained weights and "
+                  "running statistics, eval mode; the reference itself needs pytorchcv (absent) for this backbone"}
+
+
+def cpu_baseline(batch, num_classes, steps=3):
+    """fp32 CPU oracle port timed on this box's host cores: one warm-up step at batch 8, then `steps` timed
+    steps at `batch` images (bounded sample of the same workload)."""
     nbdt_path.add(oracle=True)
     import nbdt_oracle as O
     import torch_models as TM
@@ -79,11 +133,13 @@ def cpu_baseline(batch, num_classes):
 
     step(8)
     t0 = time.perf_counter()
-    step(batch)
+    for _ in range(steps):
+        step(batch)
     dt = time.perf_counter() - t0
-    return {"value": round(batch / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 training step of fp32 torch-CPU WRN-28-10 + oracle SoftTreeSupLoss at batch {batch} "
-                      f"({dt:.1f} s), after a batch-8 warm-up"}
+    return {"value": round(steps * batch / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{steps} training steps of fp32 torch-CPU WRN-28-10 + oracle SoftTreeSupLoss at batch {batch} "
+                      f"({dt:.1f} s), after a batch-8 warm-up; a port because the reference's WRN lives in "
+                      "pytorchcv and /root/reference does not exist on the GPU box"}
 
 
 def main():
@@ -96,7 +152,10 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--agreement-n", type=int, default=512, help="images in the prediction-agreement check (0: skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     from nbdt import dist as ndist
     from nbdt import engine as E
@@ -152,10 +211,20 @@ def main():
         ops.set_timer(None)
         eng.set_overlap(True)
 
+    dt_nocomm = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # what the gradient exchange costs a step: the same loop without it (ranks drift apart, nothing after
+        # this point reads the weights except the per-rank roofline pass above, which already ran)
+        nc_steps = min(args.steps, 5)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(nc_steps):
+            E.train_step(eng, crit, img, y, lr, comm=None)
+        sync()
+        dt_nocomm = (time.perf_counter() - t1) / nc_steps
+        t = torch.tensor([dt, dt_nocomm], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
+        dt, dt_nocomm = t.tolist()
     if rank != 0:
         return
 
@@ -172,15 +241,22 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": round(loss_val, 4)},
         "step_mfma_frac": round(value / world * GFLOP_PER_IMG_TRAIN / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
+    if world > 1:
+        out["comm"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                       "allreduce_bytes_per_rank": int(eng.store.grad.numel()) * 4, "buckets": 3,
+                       "ms_per_step_without_allreduce": round(1e3 * dt_nocomm, 3),
+                       "allreduce_ms_exposed": round(ms - 1e3 * dt_nocomm, 3)}
     if timer is not None:
         summ = timer.summary()
+        traffic, traffic_src = pmc_traffic()
         k = summ.get("conv_igemm")
         if k:
             out["roofline"] = {"bound": "mfma",
                                "kernel": "conv_igemm: conv3x3_halo_kernel / conv_igemm_dma_kernel (forward + "
                                          "data-gradient implicit GEMM, 2/3 of the step's flops)",
                                "achieved": round(k["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                               "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "avg_launch_us": round(k["avg_us"], 1),
                                "launches_per_step": k["launches"] // roof_steps,
                                "flops_per_launch_avg": k["flops"] / k["launches"],
@@ -195,6 +271,8 @@ def main():
                                      "avg_launch_us": round(w["avg_us"], 1),
                                      "launches_per_step": w["launches"] // roof_steps}
             out["step_ms_in_mfma_kernels"] = round((k["ms"] + w["ms"]) / roof_steps, 3) if k else None
+    if world == 1 and args.agreement_n > 0:
+        out["agreement"] = agreement(eng, args.classes, args.agreement_n, dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.classes)
     print(json.dumps(out))

@@ -200,18 +200,29 @@ class TreeHandle:
             pass
 
 
-def _rows(z):
-    """[B, C] tensor with unit column stride -> (tensor, B, ldz)."""
+def _rows(z, handle):
+    """[B, C] tensor with unit column stride -> (tensor, B, ldz).  C must be the hierarchy's class count: the
+    kernels index columns by class, so wider logits would be silently truncated and narrower ones over-read."""
     if z.dim() != 2:
         raise NBDTHipError(f"rules layer expects [B, C] logits, got shape {tuple(z.shape)}")
+    if z.shape[1] != handle.flat.num_classes:
+        raise NBDTHipError(f"logits have {z.shape[1]} columns but the hierarchy has {handle.flat.num_classes} classes")
     if z.stride(1) != 1 or (z.shape[0] > 1 and z.stride(0) < z.shape[1]):
         z = z.contiguous()
     return z, z.shape[0], (z.stride(0) if z.shape[0] > 1 else z.shape[1])
 
 
+def _class_targets(y, z):
+    if y.is_floating_point() or y.dim() != 1:
+        raise NBDTHipError("the fused tree losses take class-index targets [B]; soft / probability targets go "
+                           "through the composed path (pass a criterion that is not a default CrossEntropyLoss)")
+    return y.to(device=z.device, dtype=torch.int64).contiguous()
+
+
 def soft_forward(handle, z):
     require_gpu(z, "soft_forward")
-    z, B, ld = _rows(z)
+    handle.flat.require_single_path()
+    z, B, ld = _rows(z, handle)
     P = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
     check(lib().nbdt_soft_forward(handle.h, ptr(z), ztype_of(z), B, ld, ptr(P), stream_of(z)))
     return P
@@ -219,7 +230,8 @@ def soft_forward(handle, z):
 
 def soft_backward(handle, z, gP):
     require_gpu(z, "soft_backward")
-    z, B, ld = _rows(z)
+    handle.flat.require_single_path()
+    z, B, ld = _rows(z, handle)
     gP = gP.contiguous().float()
     gz = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
     check(lib().nbdt_soft_backward(handle.h, ptr(z), ztype_of(z), B, ld, ptr(gP), ptr(gz), stream_of(z)))
@@ -229,8 +241,9 @@ def soft_backward(handle, z, gP):
 def soft_tree_loss(handle, z, y, w_xent, w_tree, grad_scale=1.0):
     """Returns (loss scalar tensor, gz [B,C] fp32)."""
     require_gpu(z, "soft_tree_loss")
-    z, B, ld = _rows(z)
-    y = y.to(device=z.device, dtype=torch.int64).contiguous()
+    handle.flat.require_single_path()
+    z, B, ld = _rows(z, handle)
+    y = _class_targets(y, z)
     row = torch.empty((B,), dtype=torch.float32, device=z.device)
     loss = torch.empty((), dtype=torch.float32, device=z.device)
     gz = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
@@ -243,8 +256,8 @@ def soft_tree_loss(handle, z, y, w_xent, w_tree, grad_scale=1.0):
 def hard_tree_loss(handle, z, y, w_xent, w_node, grad_scale=1.0):
     """HardTreeSupLoss fused: returns (loss scalar tensor, gz [B,C] fp32)."""
     require_gpu(z, "hard_tree_loss")
-    z, B, ld = _rows(z)
-    y = y.to(device=z.device, dtype=torch.int64).contiguous()
+    z, B, ld = _rows(z, handle)
+    y = _class_targets(y, z)
     row = torch.empty((B,), dtype=torch.float32, device=z.device)
     loss = torch.empty((), dtype=torch.float32, device=z.device)
     gz = torch.empty((B, handle.flat.num_classes), dtype=torch.float32, device=z.device)
@@ -257,7 +270,7 @@ def hard_tree_loss(handle, z, y, w_xent, w_node, grad_scale=1.0):
 def node_logits(handle, z):
     """[B, R] fp32 child logits of every inner node (slot-major)."""
     require_gpu(z, "node_logits")
-    z, B, ld = _rows(z)
+    z, B, ld = _rows(z, handle)
     logits = torch.empty((B, handle.flat.num_slots), dtype=torch.float32, device=z.device)
     check(lib().nbdt_node_outputs(handle.h, ptr(z), ztype_of(z), B, ld, ptr(logits), None, None, None,
                                   stream_of(z)))
@@ -274,7 +287,7 @@ def node_logits_backward(handle, gs):
 
 def hard_forward(handle, z, want_onehot=True, want_decisions=False):
     require_gpu(z, "hard_forward")
-    z, B, ld = _rows(z)
+    z, B, ld = _rows(z, handle)
     C, D = handle.flat.num_classes, handle.max_depth
     dev = z.device
     pred = torch.empty((B,), dtype=torch.int64, device=dev)
@@ -293,7 +306,7 @@ def hard_forward(handle, z, want_onehot=True, want_decisions=False):
 
 def node_outputs(handle, z):
     require_gpu(z, "node_outputs")
-    z, B, ld = _rows(z)
+    z, B, ld = _rows(z, handle)
     R, N = handle.flat.num_slots, handle.flat.num_inodes
     dev = z.device
     logits = torch.empty((B, R), dtype=torch.float32, device=dev)

@@ -812,7 +812,10 @@ class GraphedStep:
     B=512: 21.8 vs 21.8 ms) -- the ctypes launch path costs ~5 us per kernel and the CPU stays ahead of the GPU
     (2.2 ms of enqueue for a 21 ms step), so this is latency insurance for slower hosts, not a speed-up.  The learning rate and the dropout
     seed are kernel arguments baked into the graph: build one GraphedStep per learning rate, and do not use it
-    for models with dropout.  Gradient all-reduce (RCCL) is not captured: single-GPU steps only."""
+    for models with dropout.  So are the loss weights and the device pointers of the hierarchy: a replay after
+    ``criterion.set_epoch`` changed the weights (--tswe / --xwe schedules) or after the hierarchy was re-induced
+    (SoftTreeLoss) raises instead of silently using the captured ones; the captured tree handle is kept alive
+    by this object.  Gradient all-reduce (RCCL) is not captured: single-GPU steps only."""
 
     def __init__(self, engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, warmup=2):
         if getattr(engine, "dropout_rate", 0.0) > 0.0:
@@ -823,12 +826,26 @@ class GraphedStep:
         for _ in range(warmup):     # allocate every buffer, set kernel attributes, warm the allocator
             train_step(engine, criterion, self.img, self.targets, lr, momentum, weight_decay)
         torch.cuda.synchronize()
+        self._captured = self._criterion_state()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = train_step(engine, criterion, self.img, self.targets, lr, momentum, weight_decay)
             engine.join_side_stream()     # a capture must end with every forked stream joined
 
+    def _criterion_state(self):
+        """(loss weights, tree handle) the captured launches were built with; holding the handle keeps its device
+        memory alive even if the Tree drops it."""
+        c = self.criterion
+        weights = tuple(float(w) for w in c.current_weights()) if hasattr(c, "current_weights") else None
+        tree = getattr(c, "tree", None)
+        handle = tree.device_handle(self.img.device.index) if tree is not None else None
+        return weights, handle
+
     def __call__(self, img, targets):
+        weights, handle = self._criterion_state()
+        if weights != self._captured[0] or handle is not self._captured[1]:
+            raise RuntimeError("GraphedStep: the criterion's weights or hierarchy changed since capture; "
+                               "build a new GraphedStep (they are baked into the captured launches)")
         self.img.copy_(img, non_blocking=True)
         self.targets.copy_(targets, non_blocking=True)
         self.graph.replay()

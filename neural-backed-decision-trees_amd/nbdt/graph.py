@@ -61,8 +61,10 @@ class Graph:
 def write_graph(G, path):
     path = str(path)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    with open(path, "w") as f:
+    tmp = f"{path}.tmp{os.getpid()}"          # readers never see a partial file
+    with open(tmp, "w") as f:
         json.dump(G.node_link_data(), f)
+    os.replace(tmp, path)
 
 
 def get_centers_from_state_dict(state_dict):

@@ -31,6 +31,11 @@ def _is_plain_cross_entropy(criterion):
             and getattr(criterion, "label_smoothing", 0.0) == 0.0)
 
 
+def _is_class_index(targets):
+    """Soft / probability targets ([B, C] floats) take the composed path, as with the reference's criterion."""
+    return targets.dim() == 1 and not targets.is_floating_point()
+
+
 class _FusedSoftTreeLossFn(torch.autograd.Function):
     """loss, and dloss/dz computed in the same launch (saved for backward)."""
 
@@ -136,7 +141,7 @@ class SoftTreeSupLoss(TreeSupLoss):
         return self.criterion(self.rules(outputs), targets)
 
     def forward(self, outputs, targets):
-        if _is_plain_cross_entropy(self.criterion) and outputs.dim() == 2:
+        if _is_plain_cross_entropy(self.criterion) and outputs.dim() == 2 and _is_class_index(targets):
             self.assert_output_not_nbdt(outputs)
             _C.require_gpu(outputs, "SoftTreeSupLoss")
             xent_weight, tree_weight = self.current_weights()
@@ -215,7 +220,7 @@ class HardTreeSupLoss(TreeSupLoss):
         return loss
 
     def forward(self, outputs, targets):
-        if _is_plain_cross_entropy(self.criterion) and outputs.dim() == 2:
+        if _is_plain_cross_entropy(self.criterion) and outputs.dim() == 2 and _is_class_index(targets):
             self.assert_output_not_nbdt(outputs)
             _C.require_gpu(outputs, "HardTreeSupLoss")
             xent_weight, tree_weight = self.current_weights()
@@ -279,6 +284,16 @@ class SoftTreeLoss(SoftTreeSupLoss):
         offset = self.epochs - self.start_epochs
         if offset >= 0 and offset % self.update_every_epochs == 0 and self.epochs < self.update_end_epochs:
             import os
+            import torch.distributed as dist
             checkpoint_dir = self.checkpoint_path.replace(".pth", "")
             path_graph = os.path.join(checkpoint_dir, f"graph-epoch{self.epochs}.json")
-            self.tree.update_from_model(self.net, self.arch, self.tree.dataset, path_graph=path_graph)
+            # One process per GPU (main.py): every rank holds identical weights, but only ONE may write the JSON --
+            # concurrent open(path, "w") from N ranks lets a rank read a half-written file.  Rank 0 induces and
+            # writes (atomically, Tree.update_from_model), the others wait and then load what it wrote.
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if not multi or dist.get_rank() == 0:
+                self.tree.update_from_model(self.net, self.arch, self.tree.dataset, path_graph=path_graph)
+            if multi:
+                dist.barrier()
+                if dist.get_rank() != 0:
+                    self.tree.load_hierarchy(self.tree.dataset, path_graph, self.tree.path_wnids, self.tree.classes)

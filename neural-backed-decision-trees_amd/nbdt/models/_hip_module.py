@@ -19,7 +19,12 @@ class _BackboneFn(torch.autograd.Function):
         eng = module.engine
         module._sync_mirrors()
         z = eng.forward(img, training=module.training)
+        # backward() reads the activations this forward left in the engine's buffers: remember which forward
+        # that was, and whether it normalised with batch statistics (the only BatchNorm backward implemented)
+        module._fwd_generation += 1
         ctx.module = module
+        ctx.generation = module._fwd_generation
+        ctx.batch_stats = bool(module.training)
         return z.clone()
 
     @staticmethod
@@ -27,6 +32,16 @@ class _BackboneFn(torch.autograd.Function):
         module = ctx.module
         eng = module.engine
         params = module._param_list
+        if not ctx.batch_stats:
+            raise RuntimeError(
+                "HIP backbone: backward through an eval-mode forward is not supported -- the fused inference "
+                "path keeps no activations and BatchNorm backward is implemented for batch statistics only "
+                "(call net.train(), or run the eval forward under torch.no_grad())")
+        if ctx.generation != module._fwd_generation:
+            raise RuntimeError(
+                "HIP backbone: another forward ran between this output's forward and its backward; the engine "
+                "keeps ONE set of activations, so call backward() before the next forward (or use "
+                "torch.no_grad() for forwards that need no gradient)")
         if all(p.grad is None for p in params):
             eng.zero_grad()              # optimizer.zero_grad(set_to_none=True) semantics
         eng.backward(gz.contiguous().float())
@@ -53,6 +68,7 @@ class HipBackbone(nn.Module):
                 self._nbt[name] = buf
             self._attach(name, buf, is_param=False)
         self._param_list = list(self._params_by_name.values())
+        self._fwd_generation = 0
         self._seen_version = engine.store.flat._version
 
     def _attach(self, dotted, tensor, is_param):
@@ -82,6 +98,7 @@ class HipBackbone(nn.Module):
         if torch.is_grad_enabled():
             return _BackboneFn.apply(x, self, *self._param_list)
         self._sync_mirrors()
+        self._fwd_generation += 1        # a grad-free forward also overwrites the activation buffers
         return self.engine.forward(x, training=self.training).clone()
 
     def state_dict(self, *args, **kwargs):

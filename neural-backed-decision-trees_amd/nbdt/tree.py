@@ -149,7 +149,11 @@ class FlatTree:
         self.root = index[tree.root.wnid]
         node_off, slot_off, slot_cls, slot_next = [0], [0], [], []
         per_class = [[] for _ in range(C)]
+        self.multi_path_node = None      # first inner node with a class under two of its children (DAG hierarchies)
         for n in inodes:
+            under = [c for k in range(len(n.children)) for c in n.child_index_to_class_index[k]]
+            if self.multi_path_node is None and len(set(under)) != len(under):
+                self.multi_path_node = n.wnid
             for k, child in enumerate(n.children):
                 slot = len(slot_next)
                 cls = list(n.child_index_to_class_index[k])
@@ -175,6 +179,14 @@ class FlatTree:
         self.cls_off, self.cls_slot, self.slot_next = i32(cls_off), i32(cls_slot), i32(slot_next)
         self.num_slots = len(slot_next)
         self.inode_wnids = [n.wnid for n in inodes]
+
+
+    def require_single_path(self):
+        """The soft rules multiply one child probability per (node, class); a class under two children of one
+        node has no single factor.  The reference asserts the same thing per call (nbdt/model.py:237-240)."""
+        if self.multi_path_node is not None:
+            raise AssertionError("All old indices must be unique in order for this operation to be correct "
+                                 f"(node {self.multi_path_node} reaches a class through two children)")
 
 
 class Tree:

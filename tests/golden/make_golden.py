@@ -23,6 +23,9 @@ Recorded per case (dataset, hierarchy, B, seed):
   node_*       per-inode logits/probs/preds/entropy (forward_nodes) nbdt/model.py:101-123
   tree_*       the reference Tree's index maps (inode order, child->classes) nbdt/tree.py:105-125
 induced_*.npz: build_induced_graph (nbdt/graph.py:402-464) on seeded random classifier weights: node / link order
+backbone_resnet18_*.npz: the reference's own ResNet18 (nbdt/models/resnet.py:171-179) built under torch.manual_seed,
+  one train-mode batch: state-dict key list + per-tensor sums, logits, SoftTreeSupLoss loss, per-parameter gradient
+  norms, BatchNorm running statistics after the forward -- the pin for oracle/torch_models.ResNet18
 """
 import os
 import sys
@@ -212,7 +215,37 @@ def run_induced(tag, dataset, F, seed):
     print(f"induced {tag}: {len(data['nodes'])} nodes, {len(data['links'])} links -> {os.path.basename(path)}")
 
 
+def run_backbone(tag, dataset, hierarchy, num_classes, size, batch, seed):
+    """The reference's CIFAR ResNet18 is importable under the stubs: seed -> construct (default
+    initialisers consume the generator in module order) -> one train-mode forward/backward with its own
+    SoftTreeSupLoss.  Weights are re-creatable from the seed, so only digests of them are stored."""
+    from nbdt.models.resnet import ResNet18
+    torch.manual_seed(seed)
+    net = ResNet18(num_classes=num_classes)
+    net.train()
+    g = torch.Generator().manual_seed(seed + 1000)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, num_classes, (batch,), generator=g)
+    keys = list(net.state_dict().keys())
+    sums0 = np.array([float(v.double().sum()) for v in net.state_dict().values()])
+    crit = SoftTreeSupLoss(dataset=dataset, criterion=nn.CrossEntropyLoss(), hierarchy=hierarchy)
+    z = net(x)
+    loss = crit(z, y)
+    loss.backward()
+    names = [n for n, _ in net.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    sd = net.state_dict()
+    path = os.path.join(HERE, f"backbone_resnet18_{tag}.npz")
+    np.savez_compressed(path, keys=np.array(keys), param_sums=sums0, x=x.numpy(), y=y.numpy(), logits=z.detach().numpy(),
+                        loss=np.float64(loss.item()), grad_names=np.array(names), grad_norms=gnorm,
+                        bn1_running_mean=sd["bn1.running_mean"].numpy(),
+                        last_running_var=sd["layer4.1.bn2.running_var"].numpy(), seed=np.int64(seed))
+    print(f"backbone resnet18 {tag}: loss {loss.item():.6f}, {len(keys)} state-dict entries -> {os.path.basename(path)}")
+
+
 if __name__ == "__main__":
+    run_backbone("cifar10", "CIFAR10", "induced-ResNet18", 10, 32, 8, 21)
+    run_backbone("tiny200", "TinyImagenet200", "induced-ResNet18", 200, 64, 4, 22)
     for case in CASES:
         run_case(*case)
     run_induced("cifar10", "CIFAR10", 64, 11)

@@ -104,3 +104,48 @@ def test_hard_loss_and_grad_match_reference(tag, golden_dir, pkg_dir):
     loss_w, dz_w = O.hard_tree_sup_loss(t, z, y, w_xent=0.5, tree_supervision_weight=10.0)
     assert abs(loss_w - g["hloss_w"]) <= 1e-5 * abs(g["hloss_w"])
     np.testing.assert_allclose(dz_w, g["hdz_w"], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag,dataset,num_classes", [("cifar10", "CIFAR10", 10), ("tiny200", "TinyImagenet200", 200)])
+def test_backbone_oracle_resnet18_is_the_reference_resnet18(tag, dataset, num_classes, golden_dir, pkg_dir):
+    """Pins oracle/torch_models.ResNet18 to the reference's own class (nbdt/models/resnet.py:171-179, recorded by
+    make_golden.run_backbone): same seed -> the same parameters in the same state-dict order, the same train-mode
+    logits, the same SoftTreeSupLoss (numpy oracle on the oracle logits) and the same per-parameter gradient norms
+    and BatchNorm running statistics."""
+    import torch
+    import torch_models as TM
+    g = np.load(os.path.join(golden_dir, f"backbone_resnet18_{tag}.npz"))
+    torch.manual_seed(int(g["seed"]))
+    net = TM.ResNet18(num_classes=num_classes)
+    net.train()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], g["param_sums"], rtol=0, atol=1e-9)
+    x, y = torch.from_numpy(g["x"]), g["y"]
+    z = net(x)
+    np.testing.assert_allclose(z.detach().numpy(), g["logits"], rtol=1e-5, atol=1e-5)
+    otree = O.OracleTree(*O.default_paths(dataset, "induced-ResNet18", pkg_dir))
+    loss, dz = O.soft_tree_sup_loss(otree, z.detach().numpy(), y)
+    assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    z.backward(torch.from_numpy(dz))
+    names = [n for n, _ in net.named_parameters()]
+    assert names == list(g["grad_names"])
+    gn = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    np.testing.assert_allclose(gn, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    sd = net.state_dict()
+    np.testing.assert_allclose(sd["bn1.running_mean"].numpy(), g["bn1_running_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sd["layer4.1.bn2.running_var"].numpy(), g["last_running_var"], rtol=1e-5, atol=1e-6)
+
+
+def test_wrn_oracle_keys_are_the_released_checkpoint_keys():
+    """WRN-28-10 stays parity-unpinned (pytorchcv absent).  What the reference does pin is the key the released
+    checkpoints are read with: `output.weight` is the classifier key nbdt/graph.py:391 looks up in a
+    wrn28_10_cifar10 checkpoint (nbdt/model.py:32-35 lists those checkpoints), and the canonical WRN-28-10 has
+    36,454,832 conv weights in 28 convolutions."""
+    import torch_models as TM
+    sd = TM.WRN(10, 28, 10).state_dict()
+    assert sd["output.weight"].shape == (10, 640) and sd["output.bias"].shape == (10,)
+    conv = [k for k, v in sd.items() if v.dim() == 4]
+    assert len(conv) == 28 and sum(sd[k].numel() for k in conv) == 36454832
+    assert "features.init_block.weight" in sd and "features.stage3.unit4.body.conv2.conv.weight" in sd
+    assert "features.stage2.unit1.identity_conv.weight" in sd and "features.post_activ.bn.running_var" in sd

@@ -45,6 +45,9 @@ extern "C" {
 #define NBDT_F16 2
 
 const char* nbdt_last_error(void);
+/* Name of the device kernel the calling thread's last nbdt_conv_igemm* call launched ("conv3x3_pp_kernel",
+ * "conv3x3_halo_kernel", "conv_igemm_dma_kernel"): lets the parity tests assert WHICH kernel they exercised. */
+const char* nbdt_debug_last_igemm(void);
 int nbdt_version(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int nbdt_device_count(void);
@@ -131,8 +134,10 @@ typedef struct nbdt_conv_desc {
   int32_t in_bs, in_hs, in_ws, in_base;      /* element strides of the input pixel map */
   int32_t out_bs, out_hs, out_ws, out_base;  /* element strides of the output pixel map */
   int32_t accumulate;           /* 1: out += result (reads out) */
-  int32_t wide_tile;            /* hint: 1 = nothing runs next to this launch (forward pass): prefer the 512-pixel
-                                   tile that fills a CU alone; 0 = 256-pixel tiles that share a CU */
+  int32_t wide_tile;            /* dense 3x3 stride-1 launches: 0 / 1 = pick the kernel from the grid size (512-pixel
+                                   ping-pong tiles when they give >= 3/4 of the CUs a block, else 256-pixel tiles);
+                                   2 = force the 512-pixel kernel (error if the shape does not fit it), 3 = force the
+                                   256-pixel kernel.  2 / 3 exist for tests and A/B measurements. */
   int32_t reserved;
   uint64_t w_tiled;             /* 0, or device pointer to the same weights pre-arranged by nbdt_weight_tile_batched
                                    (only dense 3x3 stride-1 launches with the identity tap map use it) */

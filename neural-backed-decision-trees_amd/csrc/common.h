@@ -128,6 +128,7 @@ struct HaloGeom {
   int nwv;             // waves per block: 4 (256-pixel tile) or 8 (512-pixel tile)
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
+extern thread_local const char* g_last_igemm;   // name of the kernel the last nbdt_conv_igemm* call launched (tests)
 struct BnBwdArgs;
 int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
                  const void* res, float* stats, const BnBwdArgs* bn, int M, hipStream_t st);

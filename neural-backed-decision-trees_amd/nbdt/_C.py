@@ -61,6 +61,7 @@ SIGNATURES = {
                                  POINTER(c_void_p)]),
     "nbdt_tree_destroy": (c_int, [c_void_p]),
     "nbdt_tree_max_depth": (c_int, [c_void_p]),
+    "nbdt_debug_last_igemm": (c_char_p, []),
     "nbdt_soft_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P]),
     "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,

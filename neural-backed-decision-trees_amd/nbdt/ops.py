@@ -250,6 +250,25 @@ def weight_tile_batched(src_bf16, table, n, total, dst_bf16):
                                          stream_ptr(src_bf16.device)))
 
 
+def weight_tiles(w_bf16):
+    """One [rows][9][k] bf16 weight matrix (forward weights, or the transposed data-gradient copy) re-stored as the
+    DMA-ordered tiles the dense 3x3 kernels read (desc.w_tiled): the single-matrix form of weight_tile_batched."""
+    rows, taps, k = w_bf16.shape
+    assert taps == 9 and rows % 32 == 0 and k % 32 == 0
+    r32 = rows // 32
+    nt = 5 if r32 % 5 == 0 else 4 if r32 % 4 == 0 else 2 if r32 % 2 == 0 else 1
+    total = (rows // (32 * nt)) * (k // 32) * 9
+    table = torch.tensor([[0, 0, rows, k, 0]], dtype=torch.int64, device=w_bf16.device)
+    dst = torch.empty(rows * 9 * k, dtype=torch.bfloat16, device=w_bf16.device)
+    weight_tile_batched(w_bf16.contiguous(), table, 1, total, dst)
+    return dst
+
+
+def last_igemm_kernel():
+    """Name of the device kernel this thread's last conv_igemm* call launched (tests assert on it)."""
+    return lib().nbdt_debug_last_igemm().decode()
+
+
 def weight_prep_batched(flat, table, n_layers, total, wd_flat):
     check(lib().nbdt_weight_prep_batched(ptr(flat), ptr(table), n_layers, total, ptr(wd_flat),
                                          stream_ptr(flat.device)))

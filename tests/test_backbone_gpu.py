@@ -382,3 +382,176 @@ def test_conv_with_folded_batchnorm_epilogue(H, cin, cout, k, stride, act, res):
     err = (got - ref).abs()
     assert (err <= 2 ** -7 * ref.abs() + 2e-2).all(), err.max().item()
     assert out[:, 0].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The 512-pixel ping-pong kernel (conv3x3_pp_kernel): every launch of the benched WRN-28-10 step's dense 3x3
+# convs.  (a) small shapes forced onto it (desc.wide_tile = 2) for the edge cases -- one 32-channel slice, images
+# past the end of the batch, every cout tile width, plain and DMA-ordered weights, every epilogue -- against
+# F.conv2d AND bit-for-bit against the 256-pixel kernel (same accumulation order); (b) the bench shapes themselves.
+
+def _force(desc, mode):
+    desc.wide_tile = mode
+    return desc
+
+
+PP_SMALL = [
+    # B, H, W, cin, cout
+    (2, 32, 32, 32, 160),    # NT=5, ONE slice (no next halo slice to prefetch), 16 rows per tile
+    (3, 16, 16, 64, 64),     # NT=2, 2 images per tile, second tile half empty (M tail)
+    (9, 8, 8, 160, 320),     # NT=5 x 2 cout tiles, 8 images per tile, second tile holds 1 image
+    (2, 32, 32, 64, 128),    # NT=4
+    (1, 32, 32, 96, 32),     # NT=1, 3 slices
+    (4, 16, 16, 160, 160),   # WRN stage-1 widths, 5 slices
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", PP_SMALL)
+@pytest.mark.parametrize("tiled", [False, True])
+def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout, tiled):
+    xf, xp = _rand_act(B, H, W, cin, seed=61)
+    w_oihw, w_int = _rand_weight(cout, cin, 3, seed=62)
+    wb = w_int.to(torch.bfloat16).to(DEV)
+    rf, rp = _rand_act(B, H, W, cout, seed=63)
+    ref = F.conv2d(xf.permute(0, 3, 1, 2), w_oihw, padding=1).permute(0, 2, 3, 1)
+
+    def desc(mode):
+        d = _force(ops.conv_fwd_desc(B, H, W, cin, cout, 3, 1), mode)
+        if tiled:
+            d.w_tiled = wt.data_ptr()
+        return d
+
+    wt = ops.weight_tiles(wb) if tiled else None
+    out_pp, out_h = ops.padded(B, H, W, cout, DEV), ops.padded(B, H, W, cout, DEV)
+    ops.conv_igemm(desc(2), xp, wb, out_pp)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
+    ops.conv_igemm(desc(3), xp, wb, out_h)
+    assert ops.last_igemm_kernel() == "conv3x3_halo_kernel"
+    _close_bf16(ops.interior(out_pp), ref, "pp fwd")
+    assert torch.equal(out_pp, out_h)
+    _check_border_zero(out_pp)
+    # residual + fused BatchNorm statistics epilogue
+    n_part = ((B * H * W + 255) // 256) * 2 * cout
+    part_pp = torch.full((n_part,), float("nan"), device=DEV)
+    part_h = torch.full((n_part,), float("nan"), device=DEV)
+    ops.conv_igemm(desc(2), xp, wb, out_pp, residual=rp, bn_scratch=part_pp)
+    ops.conv_igemm(desc(3), xp, wb, out_h, residual=rp, bn_scratch=part_h)
+    _close_bf16(ops.interior(out_pp), ref + rf, "pp fwd + residual")
+    assert torch.equal(out_pp, out_h)
+    m_pp, r_pp, m_h, r_h = (torch.empty(cout, device=DEV) for _ in range(4))
+    ops.bn_finalize(out_pp, part_pp, m_pp, r_pp)
+    ops.bn_finalize(out_h, part_h, m_h, r_h)
+    o = ops.interior(out_pp).float().reshape(-1, cout)
+    np.testing.assert_allclose(m_pp.cpu().numpy(), o.mean(0).cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r_pp.cpu().numpy(), (o.var(0, unbiased=False) + 1e-5).rsqrt().cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(m_pp.cpu().numpy(), m_h.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(9, 8, 8, 160, 320), (2, 32, 32, 64, 128), (4, 16, 16, 160, 160)])
+def test_pingpong_kernel_dgrad_with_bn_backward_epilogue(B, H, W, cin, cout):
+    """Data gradient through the forced 512-pixel kernel with the BatchNorm-backward sums in its epilogue (STATS
+    mode 2), DMA-ordered transposed weights: same gradient as the 256-pixel kernel bit for bit, same folded sums."""
+    _, gp = _rand_act(B, H, W, cout, seed=71)
+    xf, xp = _rand_act(B, H, W, cin, seed=72, scale=1.5)
+    w_oihw, w_int = _rand_weight(cout, cin, 3, seed=73)
+    wd = torch.empty(cin, 9, cout, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w_int.to(DEV), cout, 9, cin, None, wd)
+    wdt = ops.weight_tiles(wd)
+    g = torch.Generator().manual_seed(74)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.randn(cin, generator=g) * 0.3).to(DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * cin, device=DEV)
+    mean, rstd = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    ops.bn_stats(xp, scratch, mean, rstd)
+    outs, sums = [], []
+    for mode, name in ((2, "conv3x3_pp_kernel"), (3, "conv3x3_halo_kernel")):
+        (d,) = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 1)
+        _force(d, mode).w_tiled = wdt.data_ptr()
+        ga = ops.padded(B, H, W, cin, DEV)
+        partials = torch.full((((B * H * W + 255) // 256) * 2 * cin,), float("nan"), device=DEV)
+        ops.conv_igemm_bnbwd(d, gp, wd, ga, xp, mean, rstd, gamma, beta, partials)
+        assert ops.last_igemm_kernel() == name
+        dsum, dg, db = torch.empty(2 * cin, device=DEV), torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
+        gx = ops.padded(B, H, W, cin, DEV)
+        ops.bn_bwd_fused(ga, xp, mean, rstd, gamma, beta, partials, dsum, dg, db, gx)
+        outs.append(ga)
+        sums.append(dsum)
+    gt = gp_ref = ops.interior(gp).float().cpu().permute(0, 3, 1, 2)
+    gx_ref = F.conv_transpose2d(gt, w_oihw, padding=1).permute(0, 2, 3, 1)
+    _close_bf16(ops.interior(outs[0]), gx_ref, "pp dgrad")
+    assert torch.equal(outs[0], outs[1])
+    scale = sums[1].abs().max().item()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), sums[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+BENCH_SHAPES = [
+    # the three dense 3x3 shapes of WRN-28-10 (97 % of the step's igemm flops) at batch sizes whose grids select
+    # the ping-pong kernel on their own (>= 192 tiles of 512 pixels): B, H, W, C
+    (128, 32, 32, 160),
+    (256, 16, 16, 320),
+    (512, 8, 8, 640),
+]
+
+
+@pytest.mark.parametrize("B,H,W,C", BENCH_SHAPES)
+def test_bench_shape_conv_forward_dgrad_wgrad(B, H, W, C):
+    """What bench.py executes, at its own tile geometry: forward with residual + statistics epilogue, data
+    gradient with the BatchNorm-backward epilogue, weight gradient -- vs fp32 PyTorch on the same bf16 inputs."""
+    xf, xp = _rand_act(B, H, W, C, seed=81)
+    w_oihw, w_int = _rand_weight(C, C, 3, seed=82)
+    wb = w_int.to(torch.bfloat16).to(DEV)
+    wd = torch.empty(C, 9, C, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w_int.to(DEV), C, 9, C, None, wd)
+    wt, wdt = ops.weight_tiles(wb), ops.weight_tiles(wd)
+    rf, rp = _rand_act(B, H, W, C, seed=83)
+    gf, gp = _rand_act(B, H, W, C, seed=84)
+    xt = xf.permute(0, 3, 1, 2).requires_grad_(True)
+    wref = w_oihw.clone().requires_grad_(True)
+    ref = F.conv2d(xt, wref, padding=1)
+    ref.backward(gf.permute(0, 3, 1, 2))
+    # forward: residual + statistics, DMA-ordered weights (the engine's forward launches)
+    d = ops.conv_fwd_desc(B, H, W, C, C, 3, 1)
+    d.w_tiled = wt.data_ptr()
+    out = ops.padded(B, H, W, C, DEV)
+    partials = torch.full((((B * H * W + 255) // 256) * 2 * C,), float("nan"), device=DEV)
+    ops.conv_igemm(d, xp, wb, out, residual=rp, bn_scratch=partials)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
+    _close_bf16(ops.interior(out), ref.detach().permute(0, 2, 3, 1) + rf, "bench-shape fwd + residual")
+    _check_border_zero(out)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_finalize(out, partials, mean, rstd)
+    o = ops.interior(out).float().reshape(-1, C)
+    np.testing.assert_allclose(mean.cpu().numpy(), o.mean(0).cpu().numpy(), rtol=1e-3, atol=1e-4)
+    # plain forward without DMA-ordered weights takes the same kernel and gives the same numbers
+    out2, out3 = ops.padded(B, H, W, C, DEV), ops.padded(B, H, W, C, DEV)
+    ops.conv_igemm(ops.conv_fwd_desc(B, H, W, C, C, 3, 1), xp, wb, out2)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
+    ops.conv_igemm(d, xp, wb, out3)
+    assert torch.equal(out2, out3)
+    _close_bf16(ops.interior(out2), ref.detach().permute(0, 2, 3, 1), "bench-shape fwd")
+    # data gradient with the BatchNorm-backward epilogue
+    (dd,) = ops.conv_dgrad_descs(B, H, W, C, C, 3, 1)
+    dd.w_tiled = wdt.data_ptr()
+    g = torch.Generator().manual_seed(85)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV)
+    ops.bn_stats(xp, scratch, mean, rstd)
+    gx = ops.padded(B, H, W, C, DEV)
+    ops.conv_igemm_bnbwd(dd, gp, wd, gx, xp, mean, rstd, gamma, beta, partials)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
+    _close_bf16(ops.interior(gx), xt.grad.permute(0, 2, 3, 1), "bench-shape dgrad")
+    _check_border_zero(gx)
+    # its partial sums == sum(g'), sum(g' * xhat) with g' = gx * [bn(x) > 0]
+    dsum, dg, db = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gin = ops.padded(B, H, W, C, DEV)
+    ops.bn_bwd_fused(gx, xp, mean, rstd, gamma, beta, partials, dsum, dg, db, gin)
+    xi, gi = ops.interior(xp).float().reshape(-1, C), ops.interior(gx).float().reshape(-1, C)
+    xhat = (xi - mean) * rstd
+    gm = gi * ((xhat * gamma + beta) > 0)
+    np.testing.assert_allclose(db.cpu().numpy(), gm.sum(0).cpu().numpy(), rtol=2e-3, atol=2e-3 * gm.abs().sum(0).mean().item())
+    np.testing.assert_allclose(dg.cpu().numpy(), (gm * xhat).sum(0).cpu().numpy(), rtol=2e-3,
+                               atol=2e-3 * gm.abs().sum(0).mean().item())
+    # weight gradient (all-taps kernel at its production tile count)
+    dw = torch.zeros(C, 9, C, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(ops.conv_wgrad_desc(B, H, W, C, C, 3, 1), xp, gp, dw)
+    gw_ref = wref.grad.permute(0, 2, 3, 1).reshape(C, 9, C)
+    np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), rtol=2e-3, atol=2e-3 * gw_ref.abs().mean().item())

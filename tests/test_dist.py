@@ -57,3 +57,70 @@ def test_single_process_is_a_noop():
     flat = torch.ones(10)
     comm.all_reduce_grads(flat)
     assert comm.world_size == 1 and torch.equal(flat, torch.ones(10))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# A whole data-parallel training step on two gloo ranks: each rank runs the fp32 oracle backbone
+# + oracle SoftTreeSupLoss on ITS shard, the flat gradient goes through GradComm in the engine's bucket order,
+# SGD applies grad/world.  Expected: exactly the sequential computation "each shard through the oracle, average
+# the gradients, one SGD step" -- per-shard BatchNorm statistics included (DataParallel semantics, no SyncBN).
+
+def _flat(tensors):
+    return torch.cat([t.reshape(-1) for t in tensors])
+
+
+def _oracle_shard_grads(seed, x, y, pkg):
+    nbdt_path.add(oracle=True)
+    import nbdt_oracle as O
+    import torch_models as TM
+    torch.manual_seed(seed)
+    net = TM.WRN(10, 10, 1)
+    net.train()
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg))
+    z = net(x)
+    loss, dz = O.soft_tree_sup_loss(otree, z.detach().numpy(), y.numpy())
+    z.backward(torch.from_numpy(dz))
+    params = [p for _, p in net.named_parameters()]
+    return net, params, _flat([p.grad for p in params]), float(loss)
+
+
+def _dp_step_worker(rank, world, port, out_dir, pkg):
+    nbdt_path.add()
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    torch.set_num_threads(2)
+    from nbdt import dist as ndist
+    ndist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(7)
+    gx, gy = torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
+    x, y = ndist.shard_batch(gx, rank, world), ndist.shard_batch(gy, rank, world)
+    net, params, flat, _ = _oracle_shard_grads(11, x, y, pkg)       # same seed: identical replicas
+    comm = ndist.GradComm()
+    n = flat.numel()
+    for lo, hi in [(2 * n // 3, n), (n // 3, 2 * n // 3), (0, n // 3)]:   # backward-completion order
+        comm.reduce_range(flat, lo, hi)
+    comm.finish(flat)
+    lr, scale = 0.1, 1.0 / comm.world_size
+    with torch.no_grad():
+        off = 0
+        for p in params:
+            p -= lr * scale * flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+    np.save(os.path.join(out_dir, f"params{rank}.npy"), _flat([p.detach() for p in params]).numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_step_equals_per_shard_oracle_average(tmp_path, pkg_dir):
+    world, port = 2, _free_port()
+    mp.spawn(_dp_step_worker, args=(world, port, str(tmp_path), pkg_dir), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(7)
+    gx, gy = torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
+    grads = []
+    for r in range(world):
+        net, params, flat, _ = _oracle_shard_grads(11, gx[4 * r:4 * r + 4], gy[4 * r:4 * r + 4], pkg_dir)
+        grads.append(flat)
+    torch.manual_seed(11)
+    expect = _flat([p.detach() for p in params]) - 0.1 * (grads[0] + grads[1]) / 2     # params: same init on every rank
+    got = [np.load(tmp_path / f"params{r}.npy") for r in range(world)]
+    assert np.array_equal(got[0], got[1])                      # replicas stay bit-identical
+    np.testing.assert_allclose(got[0], expect.numpy(), rtol=1e-5, atol=1e-6)

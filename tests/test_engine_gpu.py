@@ -124,19 +124,22 @@ def test_wrn_forward_backward_matches_fp32_oracle(pkg_dir):
     print(f"worst per-tensor gradient rel-L2 error: {worst:.4f}")
 
 
-def test_every_op_is_self_consistent(pkg_dir):
+@pytest.mark.parametrize("blocks,width,B", [(10, 2, 16), (28, 10, 128)])
+def test_every_op_is_self_consistent(blocks, width, B, pkg_dir):
     """Element-level parity on REAL network tensors: every kernel's output is recomputed with the
     plain fp32 PyTorch op from the engine's OWN stored inputs (so no cross-implementation ReLU-mask
-    chaos) and must match within bf16 storage rounding (relative L2 < 1%)."""
+    chaos) and must match within bf16 storage rounding (relative L2 < 1%).  The second case is the benched
+    network itself, WRN-28-10, at a batch (128) whose stage-1 launches select the 512-pixel ping-pong kernel and
+    whose stage-2/3 launches the 256-pixel one."""
     import torch.nn.functional as F
     from nbdt import ops
-    ref, eng = _pair(10, 2, 10, seed=7)
+    eng = E.WRNEngine(num_classes=10, blocks=blocks, width_factor=width, device=DEV, seed=7)
     eng.debug_keep = True
     crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
                            hierarchy="induced-wrn28_10_cifar10")
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(16, 3, 32, 32, generator=g)
-    y = torch.randint(0, 10, (16,), generator=g)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
     eng.zero_grad()
     z = eng.forward(x.to(DEV), training=True)
     _, gz = crit.loss_and_grad(z, y.to(DEV))
@@ -152,7 +155,6 @@ def test_every_op_is_self_consistent(pkg_dir):
     for u in eng.units:
         k, s = u["key"], u["stride"]
         cr, co = u["cin"], u["cout"]
-        B = 16
         bufs = {kk[0]: v for kk, v in eng._bufs.items() if isinstance(kk[0], str) and kk[0].startswith(k + ".")}
         a1, t, a2 = nchw(bufs[k + ".a1"])[:, :cr], nchw(bufs[k + ".t"]), nchw(bufs[k + ".a2"])
         x_in, x_out = nchw(u["x_in"])[:, :cr], nchw(u["x_out"])

@@ -161,3 +161,28 @@ def test_fused_inference_path_equals_the_unfused_one(arch):
     eng.fuse_eval = True
     z2 = eng.forward(x, training=False)
     assert (z2 - zf).abs().max().item() > 0
+
+
+def test_backward_refuses_stale_or_eval_mode_activations():
+    """The engine keeps ONE set of activations and only the batch-statistics BatchNorm backward: a backward that
+    would silently read another forward's activations, or differentiate an eval-mode forward, must raise."""
+    model = ResNet18(num_classes=10)
+    crit = nn.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(4, 3, 32, 32, generator=g).to(DEV), torch.randn(4, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (4,), generator=g).to(DEV)
+    model.train()
+    la = crit(model(a), y)
+    lb = crit(model(b), y)                   # second forward overwrites the activations of the first
+    lb.backward()                            # the most recent forward differentiates fine
+    with pytest.raises(RuntimeError, match="another forward ran"):
+        la.backward()
+    la = crit(model(a), y)
+    with torch.no_grad():
+        model(b)                             # a grad-free forward overwrites them too
+    with pytest.raises(RuntimeError, match="another forward ran"):
+        la.backward()
+    model.eval()
+    le = crit(model(a), y)
+    with pytest.raises(RuntimeError, match="eval-mode forward"):
+        le.backward()

@@ -278,3 +278,28 @@ def test_soft_tree_loss_reinduces_the_hierarchy(tmp_path, pkg_dir):
     np.testing.assert_allclose(zz.grad.cpu().numpy(), dzo, atol=1e-6, rtol=0)
     crit.set_epoch(3, 10)                              # not an update epoch: same hierarchy
     assert not os.path.exists(tmp_path / "ckpt-x" / "graph-epoch3.json")
+
+
+def test_shape_and_target_contracts(pkg_dir):
+    """Logits must have exactly the hierarchy's class count (wider ones used to be truncated silently); floating
+    point (probability) targets never reach the fused class-index kernels: nn.CrossEntropyLoss semantics through
+    the composed path instead."""
+    from nbdt import _C
+    from nbdt.loss import SoftTreeSupLoss
+    from nbdt.model import SoftEmbeddedDecisionRules
+    from nbdt.tree import Tree
+    tree = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
+    rules = SoftEmbeddedDecisionRules(tree=tree)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(6, 10, generator=g).cuda()
+    for bad in (torch.randn(6, 12).cuda(), torch.randn(6, 9).cuda()):
+        with pytest.raises(_C.NBDTHipError, match="classes"):
+            rules(bad)
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), tree=tree)
+    y = torch.randint(0, 10, (6,), generator=g).cuda()
+    hard_loss = crit(z, y)
+    onehot = torch.nn.functional.one_hot(y, 10).float()
+    soft_loss = crit(z, onehot)              # probability targets: composed path, same value for one-hot rows
+    assert abs(hard_loss.item() - soft_loss.item()) < 1e-5 * abs(hard_loss.item())
+    with pytest.raises(_C.NBDTHipError, match="class-index"):
+        crit.loss_and_grad(z, onehot)

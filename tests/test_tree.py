@@ -55,3 +55,25 @@ def test_reference_api_surface():
     assert Tree("CIFAR100").path_graph.endswith("hierarchies/CIFAR100/graph-induced.json")
     with pytest.raises(FileNotFoundError):
         Tree("CIFAR10", hierarchy="does-not-exist")
+
+
+def test_multi_path_hierarchies_are_rejected_by_the_soft_rules(tmp_path):
+    """A DAG in which one node reaches a class through two of its children has no single path probability: the
+    reference asserts per call (nbdt/model.py:237-240); here the flattened tree records it and the soft entry
+    points raise the same assertion (the hard losses keep the first-child convention)."""
+    import json
+    from nbdt.tree import Tree
+    wn = tmp_path / "wnids.txt"
+    wn.write_text("a\nb\nc\n")
+    nodes = [{"id": n} for n in ("root", "x", "y", "a", "b", "c")]
+    links = [{"source": s, "target": t} for s, t in
+             (("root", "x"), ("root", "y"), ("x", "a"), ("x", "b"), ("y", "b"), ("y", "c"))]
+    gp = tmp_path / "graph.json"
+    gp.write_text(json.dumps({"directed": True, "multigraph": False, "graph": {}, "nodes": nodes, "links": links}))
+    tree = Tree("CIFAR10", path_graph=str(gp), path_wnids=str(wn), classes=["a", "b", "c"])
+    assert tree.flat.multi_path_node == "root"
+    with pytest.raises(AssertionError, match="unique"):
+        tree.flat.require_single_path()
+    single = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
+    assert single.flat.multi_path_node is None
+    single.flat.require_single_path()

@@ -61,6 +61,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // stays scalar arithmetic and the lane part is one VGPR.  The pad before the load covers "VALU wrote the SGPR
 // (readfirstlane / readlane) -> VMEM reads it as base" (5 wait states; hipcc does not pad inside an asm string).
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+#ifdef NBDT_GLDS_LEAN
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  return;
+#endif
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -82,10 +86,16 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 //                   the gradient tensor is not re-read, x is read once, coalesced, right here)
 //   3  inference: eval-mode BatchNorm (running statistics folded into a per-channel scale/shift) and the
 //                activation applied to the accumulators -- the BatchNorm/activation pass disappears
+#ifdef NBDT_EPI_TIMING
+#define NBDT_EPI_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); epi_t[i] = (unsigned)t_; }
+#else
+#define NBDT_EPI_STAMP(i)
+#endif
 template <int NT, bool HAS_RES, int STATS, int NWV = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
                                               unsigned char* smem, int m0, int n0, int m_blk, int wave, int lane,
-                                              int tid) {
+                                              int tid, unsigned* epi_t = nullptr) {
+  NBDT_EPI_STAMP(0)
   constexpr int BN = 32 * NT;
   constexpr int NTHR = 64 * NWV;
   const nbdt_conv_desc& d = p.d;
@@ -118,6 +128,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
       __syncthreads();   // block-uniform: zeroed before any wave's atomics
     }
   }
+  NBDT_EPI_STAMP(1)
   const int ch = lane % NCH, rl = lane / NCH;
   const bool walker = rl < RL;
   float s1[8], s2[8];
@@ -137,17 +148,27 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
 
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
+    // Row offsets of this lane's ROW_ITERS rows, fetched from LDS in ONE batch.  (The first version read
+    // row_off[] inside every loop below: each iteration was  ds_read -> wait -> [ds_read_b128 -> wait] -> store,
+    // two LDS round trips per row, 12 rows, twice: 8 k cycles of a 72 k-cycle tile, measured with s_memtime.)
+    int offs[ROW_ITERS];
+    bool live[ROW_ITERS];
+#pragma unroll
+    for (int it = 0; it < ROW_ITERS; ++it) {
+      int r = rl + it * RL;
+      r = r < 32 ? r : 31;
+      offs[it] = walker ? row_off[tm * 32 + r] : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < ROW_ITERS; ++it) {
+      live[it] = rl + it * RL < 32 && offs[it] >= 0;
+      offs[it] = offs[it] >= 0 ? offs[it] : p.d.out_base + n0;     // rows past M: harmless in-bounds address
+    }
     if (HAS_RES) {  // (1) residual rows -> LDS, coalesced; all loads issued before the first LDS write
-      if (walker) {   // (unconditional loads: rows past M re-read row 0, their results are never stored)
+      if (walker) {
         u32x4_t rv[ROW_ITERS];
 #pragma unroll
-        for (int it = 0; it < ROW_ITERS; ++it) {
-          int r = rl + it * RL;
-          r = r < 32 ? r : 31;
-          int o = row_off[tm * 32 + r];
-          o = o >= 0 ? o : p.d.out_base + n0;
-          rv[it] = *(const u32x4_t*)(p.res + o + ch * 8);
-        }
+        for (int it = 0; it < ROW_ITERS; ++it) rv[it] = *(const u32x4_t*)(p.res + offs[it] + ch * 8);
 #pragma unroll
         for (int it = 0; it < ROW_ITERS; ++it) {
           const int r = rl + it * RL;
@@ -190,48 +211,51 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
         pk[1] = pack_bf16x2(v2, v3);
         *(u32x2*)at = pk;
       }
-    // (3) walk the rows: coalesced 16-byte stores (+ statistics of the rounded values)
+    NBDT_EPI_STAMP(2 + 2 * tm)
+    // (3) walk the rows: coalesced 16-byte stores (+ statistics of the rounded values).  Three batches -- BN-input
+    // loads, LDS row reads, stores -- so every load of a batch is in flight before the first wait.
     if (walker) {
       u32x4_t xv[STATS == 2 ? ROW_ITERS : 1];
-      if (STATS == 2) {   // the BatchNorm input rows, all loads in flight before the first use
+      if (STATS == 2) {
 #pragma unroll
-        for (int it = 0; it < ROW_ITERS; ++it) {
-          int r = rl + it * RL;
-          r = r < 32 ? r : 31;
-          int o = row_off[tm * 32 + r];
-          o = o >= 0 ? o : p.d.out_base + n0;
-          xv[it] = *(const u32x4_t*)(p.bn_x + o + ch * 8);
-        }
+        for (int it = 0; it < ROW_ITERS; ++it) xv[it] = *(const u32x4_t*)(p.bn_x + offs[it] + ch * 8);
       }
+      u32x4_t ov[ROW_ITERS];
 #pragma unroll
       for (int it = 0; it < ROW_ITERS; ++it) {
-        const int r = rl + it * RL;
-        if (r < 32) {
-          const int o = row_off[tm * 32 + r];
-          if (o >= 0) {
-            const u32x4_t v = *(const u32x4_t*)(region + r * PITCH + ch * 16);
-            *(u32x4_t*)(p.out + o + ch * 8) = v;
-            if (STATS == 1) {
-              float f[8];
-              unpack8(v, f);
+        int r = rl + it * RL;
+        r = r < 32 ? r : 31;
+        ov[it] = *(const u32x4_t*)(region + r * PITCH + ch * 16);
+      }
 #pragma unroll
-              for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
-            }
-            if (STATS == 2) {
-              float f[8], fx[8];
-              unpack8(v, f);
-              unpack8(xv[it], fx);
+      for (int it = 0; it < ROW_ITERS; ++it)
+        if (live[it]) *(u32x4_t*)(p.out + offs[it] + ch * 8) = ov[it];
+      if (STATS == 1) {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const float gg = (fx[i] * bsc[i] + bsh[i]) > 0.f ? f[i] : 0.f;
-                s1[i] += gg;
-                s2[i] += gg * ((fx[i] - bmu[i]) * brs[i]);
-              }
-            }
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          float f[8];
+          unpack8(ov[it], f);
+          const float m = live[it] ? 1.f : 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float v = f[i] * m; s1[i] += v; s2[i] += v * v; }
+        }
+      }
+      if (STATS == 2) {
+#pragma unroll
+        for (int it = 0; it < ROW_ITERS; ++it) {
+          float f[8], fx[8];
+          unpack8(ov[it], f);
+          unpack8(xv[it], fx);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float gg = (live[it] && (fx[i] * bsc[i] + bsh[i]) > 0.f) ? f[i] : 0.f;
+            s1[i] += gg;
+            s2[i] += gg * ((fx[i] - bmu[i]) * brs[i]);
           }
         }
       }
     }
+    NBDT_EPI_STAMP(3 + 2 * tm)
   }
   if (STATS == 1 || STATS == 2) {
     if (walker)

@@ -66,6 +66,28 @@ __device__ __forceinline__ TileOrigin tile_origin(const nbdt_conv_desc& d, const
   return o;
 }
 
+#ifndef NBDT_PP_SCHED
+#define NBDT_PP_SCHED 0    // schedule experiments: 1 no s_setprio around the MFMA segment, 2 no MFMA/VALU interleave
+                           // directives, 4 per-block rotation of the weight pieces
+#endif
+#ifndef NBDT_PP_TIMING
+#define NBDT_PP_TIMING 0   // 1: s_memtime stamps around the segments of every step, per-wave sums in g_pp_timing
+#endif
+#if NBDT_PP_TIMING
+__device__ unsigned g_pp_epi[8192 * 8];        // [block*8 + wave][8]: epilogue phases
+extern "C" int nbdt_debug_pp_epi(unsigned* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_epi), sizeof(unsigned) * 8192 * 8);
+}
+__device__ unsigned g_pp_timing[8192 * 8];     // [block*8 + wave][8]: load segment, barrier 1, MFMA segment, barrier 2, total, steps
+extern "C" int nbdt_debug_pp_timing(unsigned* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_timing), sizeof(unsigned) * 8192 * 8);
+}
+__device__ __forceinline__ unsigned stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (unsigned)t;
+}
+#endif
 #ifndef NBDT_PP_ABLATE
 #define NBDT_PP_ABLATE 0   // compile-time timing experiments (scratch/ablate_pp.sh): 1 no DMA, 2 no halo DMA after the
                            // prologue, 4 no MFMA, 8 no LDS fragment reads, 32 no epilogue stores
@@ -113,8 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
   const int a_bytes = NBDT_PIN(hg.a_bytes);
   const int a_instr = NBDT_PIN(hg.a_instr);
   const int hw2 = NBDT_PIN(hg.hw2), himg = NBDT_PIN(hg.himg);
-  const bool tiled = NBDT_PIN(p.w_tiled != nullptr ? 1 : 0) != 0;
-  const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)(tiled ? p.w_tiled : p.w);
+  const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)p.w_tiled;
   const bf16_t* in_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(in_u >> 32)) << 32) |
                                           (unsigned)NBDT_PIN((unsigned)in_u));
   const bf16_t* w_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(w_u >> 32)) << 32) |
@@ -137,27 +158,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
     px = px < last_pix ? px : last_pix;                // tail lanes / images past the batch re-read the last pixel
     glds16_s(in_base + kc * BK, (unsigned)(px * cin + a_lane_el) * 2u, lds_base + buf * a_bytes + id * 1024);
   };
-  // W piece `id` = tile rows [16 id, 16 id + 16).  Tiled weights: the tile IS the LDS image (contiguous KiB per
-  // piece: lane offset 16*lane); otherwise row-major [cout][tap][cin] with the swizzle on the source chunk.
-  const int w_row_len = d.w_ntaps * cin;
-  const int tap_w_v = lane < 9 ? d.w_tap[lane < 9 ? lane : 0] * cin : 0;   // lane t holds tap t's weight k-offset
-  unsigned w_voff[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int id = wave + NWV * k;
-    int row = id * 16 + (lane >> 2);
-    row = row < BN ? row : BN - 1;
-    w_voff[k] = tiled ? lane * 16u : (unsigned)((n0 + row) * w_row_len + (((lane & 3) ^ ((row >> 2) & 3)) << 3)) * 2u;
-  }
+  // W piece `id` = rows [16 id, 16 id + 16) of a weight tile.  The weights are the DMA-ordered tiles of
+  // nbdt_weight_tile_batched: tile (n_blk, kc, tap) IS the swizzled LDS image, stored contiguously in step order,
+  // so piece id of step t is  w_tiles + (t * W_INSTR + id) KiB  and every lane reads 16 B at 16 * lane.
+  const unsigned w_voff = lane * 16u;
   const unsigned w_ring = lds_base + 2 * a_bytes;
-  auto issue_w = [&](int slot, int tap, int kc) {
-    const int tile_el = ((n_blk * kchunks + kc) * 9 + tap) * (BN * 32);
-    const int w_k = tiled ? tile_el : __builtin_amdgcn_readlane(tap_w_v, tap) + kc * BK;
+  const bf16_t* w_tiles = w_base + (size_t)n_blk * kchunks * 9 * (BN * 32);
+  // Blocks run in lockstep (same start, same step time): without the rotation every CU of an XCD would ask its L2
+  // for the SAME KiB at the same moment.  Block b starts W_ROT pieces further into the tile.
+  const int w_rot = (NBDT_PP_SCHED & 4) ? item % W_INSTR : 0;
+  auto issue_w = [&](int slot, int t) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int id = wave + NWV * k;
-      if (id < W_INSTR)   // wave-uniform
-        glds16_s(w_base + (w_k + (tiled ? id * 512 : 0)), w_voff[k], w_ring + slot * W_BYTES + id * 1024);
+      const int slot_id = wave + NWV * k;
+      if (slot_id < W_INSTR) {   // wave-uniform
+        int id = slot_id + w_rot;
+        id = id >= W_INSTR ? id - W_INSTR : id;
+        glds16_s(w_tiles + (t * W_INSTR + id) * 512, w_voff, w_ring + slot * W_BYTES + id * 1024);
+      }
     }
   };
 
@@ -183,42 +201,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
   }
   const int w_frag_off = frag_row * 64 + ((frag_half ^ ((frag_row >> 2) & 3)) << 4);   // ks = 0; ks = 1 is ^ 32
 
+  // ---- everything a load segment needs is prepared one segment EARLIER, inside the previous MFMA segment: a wave
+  // issues one instruction per ~4 cycles, a load segment that also computed its 4 swizzled LDS addresses and its
+  // DMA operands was ~100 instructions = 840 cycles long (s_memtime stamps, profiles/r02_pp_segments.txt) and set
+  // the pace, while the MFMA segment used 20 of its 160 issue slots.  Now L(t) = reads, wait, <= 3 DMA, wait.
+  typedef const __attribute__((address_space(3))) unsigned char* lds_cptr;   // 32-bit: reads stay ds_read_b128
+  const lds_cptr smem3 = (lds_cptr)smem;
+  struct Plan {
+    lds_cptr ra[2][2];        // LDS addresses of the pixel fragments [ks][tm]
+    unsigned a_voff;          // halo piece: per-lane byte offset
+    bool a_on;                // ... and whether this wave issues one in L(t)
+  };
+  const unsigned w_rd0 = 2 * a_bytes + w_frag_off, w_rd1 = 2 * a_bytes + (w_frag_off ^ 32);
+  const int a_pix0 = base_pix + wave * 16;     // halo pixel of lane 0 of this wave's piece at tap 0
+  auto prepare = [&](int tapn, int kcn) {     // plan of L(t) for t = (kcn, tapn); tapn is a literal after unrolling
+    Plan q;
+    int h0 = hp0[0], h1 = hp0[1], lp = a_lane_pix;
+    asm volatile("" : "+v"(h0), "+v"(h1), "+v"(lp));    // the address math stays in the segment that calls prepare()
+    const int toff = (tapn / 3) * hw2 + (tapn % 3);
+    const unsigned abuf = (kcn & 1) * a_bytes;
+    {
+      const int hp = h0 + toff;
+      const unsigned o = hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4);
+      q.ra[0][0] = smem3 + (abuf + o); q.ra[1][0] = smem3 + (abuf + (o ^ 32));
+    }
+    {
+      const int hp = h1 + toff;
+      const unsigned o = hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4);
+      q.ra[0][1] = smem3 + (abuf + o); q.ra[1][1] = smem3 + (abuf + (o ^ 32));
+    }
+    // one piece of the next halo slice per wave at taps 0..6 (56 piece slots): piece id = tapn * 8 + wave
+    q.a_on = tapn < 7 && kcn + 1 < kchunks && tapn * NWV + wave < a_instr;
+    int px = lp + (a_pix0 + tapn * NWV * 16);
+    px = px < last_pix ? px : last_pix;       // tail lanes / images past the batch re-read the last pixel
+    q.a_voff = (unsigned)(px * cin + a_lane_el) * 2u;
+    return q;
+  };
+
   // ---- prologue: A(0) (every piece), W(0), W(1)
   if (!(abl & 1)) {
 #pragma unroll
     for (int k = 0; k < 7; ++k)
       if (wave + NWV * k < a_instr) issue_a_piece(0, 0, wave + NWV * k);
-    issue_w(0, 0, 0);
-    issue_w(1, 1, 0);
+    issue_w(0, 0);
+    issue_w(1, 1);
   }
+  Plan plan = prepare(0, 0);
+  bool prev_a = false;                     // did this wave issue a halo piece in the previous load segment?
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // bP
   if (grp == 1) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
+#if NBDT_PP_TIMING
+  unsigned tm_l = 0, tm_b1 = 0, tm_m = 0, tm_b2 = 0;
+  const unsigned tm_begin = stamp();
+  unsigned tm_prev = tm_begin;
+#define NBDT_STAMP(acc_) { const unsigned t_ = stamp(); acc_ += t_ - tm_prev; tm_prev = t_; }
+#else
+#define NBDT_STAMP(acc_)
+#endif
   for (int kc = 0; kc < kchunks; ++kc) {
-    const unsigned char* As = smem + (kc & 1) * a_bytes;
-    const bool more_a = kc + 1 < kchunks;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      // ================= L(t): operand fragments -> registers, DMA for later steps =================
-      const unsigned char* Ws = smem + 2 * a_bytes + (tap % 3) * W_BYTES + w_frag_off;
-      const int toff = (tap / 3) * hw2 + (tap % 3);
+      // ================= L(t): fragments -> registers, this wave's DMA pieces =================
       bf16x8 pf[2][2], wf[2][NT];
       if (!(abl & 8)) {
-        int hq[2] = {hp0[0], hp0[1]};
-        asm volatile("" : "+v"(hq[0]), "+v"(hq[1]));   // per-tap LDS addresses are computed here, not hoisted
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
-          const int hp = hq[tm] + toff;
-          const int o = hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4);
-          pf[0][tm] = *(const bf16x8*)(As + o);
-          pf[1][tm] = *(const bf16x8*)(As + (o ^ 32));
+          pf[0][tm] = *(const __attribute__((address_space(3))) bf16x8*)plan.ra[0][tm];
+          pf[1][tm] = *(const __attribute__((address_space(3))) bf16x8*)plan.ra[1][tm];
         }
 #pragma unroll
         for (int tn = 0; tn < NT; ++tn) {
-          wf[0][tn] = *(const bf16x8*)(Ws + tn * 2048);
-          wf[1][tn] = *(const bf16x8*)((Ws + tn * 2048) + ((w_frag_off ^ 32) - w_frag_off));
+          wf[0][tn] = *(const bf16x8*)(smem + w_rd0 + ((tap % 3) * W_BYTES + tn * 2048));
+          wf[1][tn] = *(const bf16x8*)(smem + w_rd1 + ((tap % 3) * W_BYTES + tn * 2048));
         }
       } else {
 #pragma unroll
@@ -232,25 +289,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
       // Wait for the weight pieces this wave issued one step ago.  A halo piece issued in that step came LAST in
       // issue order and is not needed before the next slice: it may stay in flight (vmcnt counts in order), so
       // its HBM latency is never exposed; the next step's wait retires it.
-      const bool a_prev = tap >= 1 && tap <= 7 && more_a && (tap - 1) * NWV + wave < a_instr;   // wave-uniform
-      if (a_prev) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      if (prev_a) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!(abl & 1)) {
-        if (tap < 7) {                                      // W(t+2): same slice
-          issue_w((tap + 2) % 3, tap + 2, kc);
-        } else if (more_a) {                                // W(t+2): first taps of the next slice
-          issue_w((tap + 2) % 3, tap - 7, kc + 1);
-        }
-        if (!(abl & 2) && tap < 7 && more_a && tap * NWV + wave < a_instr)
-          issue_a_piece((kc + 1) & 1, kc + 1, tap * NWV + wave);
+        const int t2 = kc * 9 + tap + 2;                    // W(t+2) -> ring slot (t+2) % 3 = (tap+2) % 3
+        if (t2 < nk) issue_w((tap + 2) % 3, t2);
+        if (!(abl & 2) && plan.a_on)                        // piece tap*8 + wave of slice kc+1
+          glds16_s(in_base + (kc + 1) * BK, plan.a_voff, lds_base + ((kc + 1) & 1) * a_bytes + (tap * NWV + wave) * 1024);
       }
+      prev_a = plan.a_on && !(abl & 3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      NBDT_STAMP(tm_l)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // ================= M(t): 4*NT MFMAs, nothing else =================
+      NBDT_STAMP(tm_b1)
+      // ================= M(t): 4*NT MFMAs; the idle issue slots between them prepare L(t+1) =================
+      if (!(NBDT_PP_SCHED & 1)) __builtin_amdgcn_s_setprio(1);
+      plan = tap < 8 ? prepare(tap + 1, kc) : prepare(0, kc + 1);     // (after the last step: computed, never used)
       if (!(abl & 4)) {
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -258,18 +315,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
               acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][tn], pf[ks][tm], acc[tn][tm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
       }
+      // one MFMA, then at most two of the preparation's VALU / SALU instructions in its shadow, 20 times
+      if (!(NBDT_PP_SCHED & 2)) {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+          __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
+        }
+      }
+      asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[0][1]), "+v"(plan.ra[1][0]), "+v"(plan.ra[1][1]), "+v"(plan.a_voff));
+      if (!(NBDT_PP_SCHED & 1)) __builtin_amdgcn_s_setprio(0);
+      NBDT_STAMP(tm_m)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      NBDT_STAMP(tm_b2)
     }
   }
+#if NBDT_PP_TIMING
+  if (lane == 0 && item < 1024) {
+    unsigned* o = g_pp_timing + (item * 8 + wave) * 8;
+    o[0] = tm_l; o[1] = tm_b1; o[2] = tm_m; o[3] = tm_b2; o[4] = tm_prev - tm_begin; o[5] = nk;
+  }
+#endif
+#undef NBDT_STAMP
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
+#if NBDT_PP_TIMING
+  unsigned epi_t[8];
+  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid, epi_t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores acknowledged
+  epi_t[6] = stamp();
+  if (lane == 0 && item < 1024)
+    for (int i = 0; i < 6; ++i) g_pp_epi[(item * 8 + wave) * 8 + i] = epi_t[i + 1] - epi_t[i];
+#else
   if (!(abl & 32)) conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
-  else {   // timing experiment: no epilogue, but every accumulator stays live
+#endif
+  if (abl & 32) {   // timing experiment: no epilogue, but every accumulator stays live
     float sum = 0.f;
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
@@ -545,8 +630,14 @@ bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
   if (d->in_ws != d->cin || d->in_hs != (d->gw + 2) * d->cin || d->in_bs != (d->gh + 2) * d->in_hs) return false;
   for (int t = 0; t < 9; ++t)
     if (d->tap_off[t] != (t / 3) * d->in_hs + (t % 3) * d->in_ws) return false;
+  // the halo kernels address the input with 32-bit byte offsets from the tensor base
+  if ((long long)d->B * d->in_bs * 2 >= (1ll << 32)) return false;
+  // the ping-pong kernel reads DMA-ordered weight tiles only (every engine launch has them; a caller without
+  // them gets the 256-pixel kernel, which also reads the plain [cout][tap][cin] layout)
+  bool tiled = d->w_tiled != 0 && d->w_ntaps == 9;
+  for (int t = 0; t < 9; ++t) tiled = tiled && d->w_tap[t] == t;
   const long long tiles512 = ((long long)M + 511) / 512 * (d->cout / (32 * cout_tile(d->cout)));
-  const bool want_wide = d->wide_tile == 2 || (d->wide_tile != 3 && tiles512 >= 192);
+  const bool want_wide = tiled && (d->wide_tile == 2 || (d->wide_tile != 3 && tiles512 >= 192));
   if (want_wide && halo_geom_for(d, 512, 8, hg)) return true;
   if (d->wide_tile == 2) return false;
   return halo_geom_for(d, 256, 4, hg);

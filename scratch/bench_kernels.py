@@ -28,14 +28,18 @@ for (H, cin, cout, k, st) in shapes:
     wb = w.to(torch.bfloat16); wd = torch.empty(cin, k * k, cout, dtype=torch.bfloat16, device=DEV)
     ops.weight_prep(w, cout, k * k, cin, None, wd)
     out = ops.padded(B, Ho, Ho, cout, DEV); gx = ops.padded(B, H, H, cin, DEV)
+    wt = ops.weight_tiles(wb) if (k == 3 and st == 1) else None
+    wdt = ops.weight_tiles(wd) if (k == 3 and st == 1) else None
     dw = torch.zeros(cout, k * k, cin, device=DEV)
     flops = 2.0 * B * Ho * Ho * cout * cin * k * k
     line = f"H={H} {cin}->{cout} k{k} s{st}: "
     if 'fwd' in which:
         d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
+        if wt is not None: d.w_tiled = wt.data_ptr()
         t = timeit(lambda: ops.conv_igemm(d, x, wb, out)); line += f"fwd {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
     if 'epi' in which:
         d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
+        if wt is not None: d.w_tiled = wt.data_ptr()
         scr = torch.zeros(((B * Ho * Ho + 255) // 256) * 2 * cout, device=DEV)
         res = ops.padded(B, Ho, Ho, cout, DEV); ops.interior(res).normal_()
         fns = [lambda: ops.conv_igemm(d, x, wb, out), lambda: ops.conv_igemm(d, x, wb, out, residual=res),
@@ -48,6 +52,7 @@ for (H, cin, cout, k, st) in shapes:
         line += "  ".join(f"{n} {min(t)*1e6:.0f}/{max(t)*1e6:.0f}us" for n, t in zip(("plain", "+res", "+stats", "+both"), ts))
     if 'dgrad' in which:
         ds = ops.conv_dgrad_descs(B, H, H, cin, cout, k, st)
+        if wdt is not None: ds[0].w_tiled = wdt.data_ptr()
         t = timeit(lambda: [ops.conv_igemm(d, g, wd, gx) for d in ds]); line += f"dgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
     if 'wgrad' in which:
         d = ops.conv_wgrad_desc(B, H, H, cin, cout, k, st)

@@ -19,7 +19,7 @@ def trace(db):
     for r in con.execute("select name, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size, grid_x, workgroup_x from kernels group by name"):
         if 'conv' in r[0]: print('   ', r[0][:50], 'lds', r[1], 'vgpr', r[2], 'agpr', r[3], 'sgpr', r[4], 'scratch', r[5], 'grid', r[6], 'wg', r[7])
 for d in sys.argv[1:]:
-    for db in sorted(glob.glob(d + '/*/*.db')):
+    for db in sorted(glob.glob(d + '/*/*.db') + glob.glob(d + '/*.db')):
         print('==', db)
         if '/trace/' in db: trace(db)
         else: report(db)

@@ -407,8 +407,8 @@ PP_SMALL = [
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", PP_SMALL)
-@pytest.mark.parametrize("tiled", [False, True])
-def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout, tiled):
+def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout):
+    tiled = True       # the ping-pong kernel reads DMA-ordered weight tiles only (the 256-pixel one reads both)
     xf, xp = _rand_act(B, H, W, cin, seed=61)
     w_oihw, w_int = _rand_weight(cout, cin, 3, seed=62)
     wb = w_int.to(torch.bfloat16).to(DEV)
@@ -427,6 +427,11 @@ def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout, tiled):
     assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
     ops.conv_igemm(desc(3), xp, wb, out_h)
     assert ops.last_igemm_kernel() == "conv3x3_halo_kernel"
+    plain = ops.padded(B, H, W, cout, DEV)       # no tiles: the 256-pixel kernel on the plain weight layout
+    ops.conv_igemm(ops.conv_fwd_desc(B, H, W, cin, cout, 3, 1), xp, wb, plain)
+    assert ops.last_igemm_kernel() == "conv3x3_halo_kernel" and torch.equal(plain, out_h)
+    with pytest.raises(Exception, match="wide_tile"):
+        ops.conv_igemm(_force(ops.conv_fwd_desc(B, H, W, cin, cout, 3, 1), 2), xp, wb, plain)
     _close_bf16(ops.interior(out_pp), ref, "pp fwd")
     assert torch.equal(out_pp, out_h)
     _check_border_zero(out_pp)
@@ -521,11 +526,12 @@ def test_bench_shape_conv_forward_dgrad_wgrad(B, H, W, C):
     ops.bn_finalize(out, partials, mean, rstd)
     o = ops.interior(out).float().reshape(-1, C)
     np.testing.assert_allclose(mean.cpu().numpy(), o.mean(0).cpu().numpy(), rtol=1e-3, atol=1e-4)
-    # plain forward without DMA-ordered weights takes the same kernel and gives the same numbers
+    # a caller without DMA-ordered weights gets the 256-pixel kernel and the same numbers bit for bit
     out2, out3 = ops.padded(B, H, W, C, DEV), ops.padded(B, H, W, C, DEV)
     ops.conv_igemm(ops.conv_fwd_desc(B, H, W, C, C, 3, 1), xp, wb, out2)
-    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
+    assert ops.last_igemm_kernel() == "conv3x3_halo_kernel"
     ops.conv_igemm(d, xp, wb, out3)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
     assert torch.equal(out2, out3)
     _close_bf16(ops.interior(out2), ref.detach().permute(0, 2, 3, 1), "bench-shape fwd")
     # data gradient with the BatchNorm-backward epilogue

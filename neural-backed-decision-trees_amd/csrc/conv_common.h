@@ -26,7 +26,6 @@ struct ConvDmaParams {
   const float *aff_scale, *aff_shift;
   int aff_act;         // 0 none, 1 ReLU, 2 swish
   int M, n_blocks, m_blocks, per_xcd;
-  int debug;           // NBDT_IGEMM_DEBUG: timing experiments only (1: no DMA, 2: no waits/barriers, 4: no MFMA)
 };
 }  // namespace nbdt
 

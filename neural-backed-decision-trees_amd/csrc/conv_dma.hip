@@ -144,24 +144,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
   advance();
   if (nk > 1) { issue(1, tap, kc); advance(); }
   int slot = 0;
-  const int dbg = __builtin_amdgcn_readfirstlane(p.debug);
   for (int t = 0; t < nk; ++t) {
-    if (!(dbg & 2)) {
-      if (t + 1 < nk) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
+    if (t + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < nk && !(dbg & 1)) {
+    if (t + 2 < nk) {
       int s2 = slot + 2;
       s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
       issue(s2, tap, kc);
       advance();
     }
-    if (!(dbg & 4)) compute(slot);
+    compute(slot);
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
   }
 
@@ -217,8 +214,6 @@ int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void*
   p.aff_scale = bn ? bn->aff_scale : nullptr; p.aff_shift = bn ? bn->aff_shift : nullptr;
   p.aff_act = bn ? bn->aff_act : 0;
   p.M = M;
-  static const int dbg = getenv("NBDT_IGEMM_DEBUG") ? atoi(getenv("NBDT_IGEMM_DEBUG")) : 0;
-  p.debug = dbg;
   const int nt32 = d->cout / 32;
   if (nt32 % 5 == 0) return launch_dma<5>(p, st);
   if (nt32 % 4 == 0) return launch_dma<4>(p, st);

@@ -104,9 +104,10 @@ __device__ __forceinline__ unsigned stamp() {
 // the barrier that precedes the first reader (group 0, L(t+2)).  A(kc+1) overwrites the buffer of A(kc-1),
 // dead since step 9kc-1; its pieces are issued at taps 0..6 of slice kc and retired by the wait two steps later
 // (tap 6 -> the vmcnt(0) of tap 8), a barrier before step 9kc+9 reads them.  Nothing but vmcnt + a barrier orders LDS-DMA against ds_read.
-template <int NT, bool HAS_RES, int STATS>
-__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams p, nbdt::HaloGeom hg) {
-  constexpr int NWV = 8;
+template <int NT, bool HAS_RES, int STATS, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams p, nbdt::HaloGeom hg) {
+  constexpr bool PP = NWV == 8;          // two wave groups alternating roles; NWV == 4: one group, two blocks per CU
+  constexpr int APW = PP ? 1 : 2;        // halo pieces a wave may issue per step (taps 0..6: 7 * NWV * APW slots)
   constexpr int BN = 32 * NT;
   constexpr int BMH = 64 * NWV;
   constexpr int W_BYTES = BN * BK * 2;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
+  const int grp = PP ? wave >> 2 : 0;
   const nbdt_conv_desc& d = p.d;
 
 #define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
@@ -167,9 +168,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
   // Blocks run in lockstep (same start, same step time): without the rotation every CU of an XCD would ask its L2
   // for the SAME KiB at the same moment.  Block b starts W_ROT pieces further into the tile.
   const int w_rot = (NBDT_PP_SCHED & 4) ? item % W_INSTR : 0;
+  constexpr int IPW = (W_INSTR + NWV - 1) / NWV;
   auto issue_w = [&](int slot, int t) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < IPW; ++k) {
       const int slot_id = wave + NWV * k;
       if (slot_id < W_INSTR) {   // wave-uniform
         int id = slot_id + w_rot;
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
   const lds_cptr smem3 = (lds_cptr)smem;
   struct Plan {
     lds_cptr ra[2][2];        // LDS addresses of the pixel fragments [ks][tm]
-    unsigned a_voff;          // halo piece: per-lane byte offset
-    bool a_on;                // ... and whether this wave issues one in L(t)
+    unsigned a_voff[APW];     // halo pieces: per-lane byte offsets
+    int a_n;                  // ... and how many of them this wave issues in L(t)
   };
   const unsigned w_rd0 = 2 * a_bytes + w_frag_off, w_rd1 = 2 * a_bytes + (w_frag_off ^ 32);
   const int a_pix0 = base_pix + wave * 16;     // halo pixel of lane 0 of this wave's piece at tap 0
@@ -230,27 +232,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
       const unsigned o = hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4);
       q.ra[0][1] = smem3 + (abuf + o); q.ra[1][1] = smem3 + (abuf + (o ^ 32));
     }
-    // one piece of the next halo slice per wave at taps 0..6 (56 piece slots): piece id = tapn * 8 + wave
-    q.a_on = tapn < 7 && kcn + 1 < kchunks && tapn * NWV + wave < a_instr;
-    int px = lp + (a_pix0 + tapn * NWV * 16);
-    px = px < last_pix ? px : last_pix;       // tail lanes / images past the batch re-read the last pixel
-    q.a_voff = (unsigned)(px * cin + a_lane_el) * 2u;
+    // up to APW pieces of the next halo slice per wave at taps 0..6: piece id = (tapn * APW + j) * NWV + wave
+    q.a_n = 0;
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+      const int id0 = (tapn * APW + j) * NWV;            // literal
+      if (tapn < 7 && kcn + 1 < kchunks && id0 + wave < a_instr) q.a_n = j + 1;
+      int px = lp + (a_pix0 + id0 * 16);
+      px = px < last_pix ? px : last_pix;     // tail lanes / images past the batch re-read the last pixel
+      q.a_voff[j] = (unsigned)(px * cin + a_lane_el) * 2u;
+    }
     return q;
   };
 
   // ---- prologue: A(0) (every piece), W(0), W(1)
   if (!(abl & 1)) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < 7 * APW; ++k)
       if (wave + NWV * k < a_instr) issue_a_piece(0, 0, wave + NWV * k);
     issue_w(0, 0);
     issue_w(1, 1);
   }
   Plan plan = prepare(0, 0);
-  bool prev_a = false;                     // did this wave issue a halo piece in the previous load segment?
+  int prev_a = 0;                          // halo pieces this wave issued in the previous load segment
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();            // bP
-  if (grp == 1) __builtin_amdgcn_s_barrier();
+  if (PP && grp == 1) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
 #if NBDT_PP_TIMING
@@ -289,15 +296,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
       // Wait for the weight pieces this wave issued one step ago.  A halo piece issued in that step came LAST in
       // issue order and is not needed before the next slice: it may stay in flight (vmcnt counts in order), so
       // its HBM latency is never exposed; the next step's wait retires it.
-      if (prev_a) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (prev_a == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (prev_a == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       if (!(abl & 1)) {
         const int t2 = kc * 9 + tap + 2;                    // W(t+2) -> ring slot (t+2) % 3 = (tap+2) % 3
         if (t2 < nk) issue_w((tap + 2) % 3, t2);
-        if (!(abl & 2) && plan.a_on)                        // piece tap*8 + wave of slice kc+1
-          glds16_s(in_base + (kc + 1) * BK, plan.a_voff, lds_base + ((kc + 1) & 1) * a_bytes + (tap * NWV + wave) * 1024);
+        if (!(abl & 2)) {                                   // pieces (tap*APW + j)*NWV + wave of slice kc+1
+#pragma unroll
+          for (int j = 0; j < APW; ++j)
+            if (j < plan.a_n)
+              glds16_s(in_base + (kc + 1) * BK, plan.a_voff[j],
+                       lds_base + ((kc + 1) & 1) * a_bytes + ((tap * APW + j) * NWV + wave) * 1024);
+        }
       }
-      prev_a = plan.a_on && !(abl & 3);
+      prev_a = (abl & 3) ? 0 : plan.a_n;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       NBDT_STAMP(tm_l)
       __builtin_amdgcn_sched_barrier(0);
@@ -325,11 +338,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
           __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
         }
       }
-      asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[0][1]), "+v"(plan.ra[1][0]), "+v"(plan.ra[1][1]), "+v"(plan.a_voff));
+      asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[0][1]), "+v"(plan.ra[1][0]), "+v"(plan.ra[1][1]), "+v"(plan.a_voff[0]));
+      if (APW == 2) asm volatile("" : "+v"(plan.a_voff[APW - 1]));
       if (!(NBDT_PP_SCHED & 1)) __builtin_amdgcn_s_setprio(0);
       NBDT_STAMP(tm_m)
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (PP) __builtin_amdgcn_s_barrier();      // (one group: L(t+1) only needs what the barrier after L(t) ordered)
       __builtin_amdgcn_sched_barrier(0);
       NBDT_STAMP(tm_b2)
     }
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams 
   }
 #endif
 #undef NBDT_STAMP
-  if (grp == 0) __builtin_amdgcn_s_barrier();
+  if (PP && grp == 0) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
 #if NBDT_PP_TIMING
@@ -534,8 +548,11 @@ namespace nbdt {
 
 thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): which kernel the last launch used
 
-template <int NT, int NWV>
+// KIND 0: conv3x3_pp_kernel<.., 8> (ping-pong), 1: conv3x3_pp_kernel<.., 4> (same segments, one group, two blocks
+// per CU), 2: conv3x3_halo_kernel (4 waves, plain weight layout)
+template <int NT, int KIND>
 static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
+  constexpr int NWV = KIND == 0 ? 8 : 4;
   constexpr int BN = 32 * NT;
   constexpr int BMH = 64 * NWV;
   p.n_blocks = p.d.cout / BN;
@@ -547,42 +564,26 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   if (shmem < epi) shmem = epi;
   static size_t attr_bytes = 0;
   const dim3 grid(p.per_xcd * 8), blk(64 * NWV);
-  if constexpr (NWV == 8) {
-    if (shmem > attr_bytes) {
-#define NBDT_ATTR(R, S)                                                                                \
-  NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S>),      \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
-      NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
-      NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
+#define NBDT_KERNEL(R, S) \
+  (KIND == 2 ? reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>) \
+             : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV>))
+  if (shmem > attr_bytes) {
+#define NBDT_ATTR(R, S) \
+  NBDT_HIP_CHECK(hipFuncSetAttribute(NBDT_KERNEL(R, S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+    NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
+    NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
 #undef NBDT_ATTR
-      attr_bytes = shmem;
-    }
-#define NBDT_GO(R, S) hipLaunchKernelGGL((conv3x3_pp_kernel<NT, R, S>), grid, blk, shmem, st, p, hg)
-    if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
-    else if (p.bn_x != nullptr) NBDT_GO(false, 2);
-    else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
-    else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
-#undef NBDT_GO
-    g_last_igemm = "conv3x3_pp_kernel";
-  } else {
-    if (shmem > attr_bytes) {
-#define NBDT_ATTR(R, S)                                                                                \
-  NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>),    \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
-      NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
-      NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
-#undef NBDT_ATTR
-      attr_bytes = shmem;
-    }
-#define NBDT_GO(R, S) hipLaunchKernelGGL((conv3x3_halo_kernel<NT, R, S>), grid, blk, shmem, st, p, hg)
-    if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
-    else if (p.bn_x != nullptr) NBDT_GO(false, 2);
-    else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
-    else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
-#undef NBDT_GO
-    g_last_igemm = "conv3x3_halo_kernel";
+    attr_bytes = shmem;
   }
-  NBDT_LAUNCH_CHECK();
+  void* args[] = {(void*)&p, (void*)&hg};
+#define NBDT_GO(R, S) NBDT_HIP_CHECK(hipLaunchKernel(NBDT_KERNEL(R, S), grid, blk, args, shmem, st))
+  if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
+  else if (p.bn_x != nullptr) NBDT_GO(false, 2);
+  else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
+  else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
+#undef NBDT_GO
+#undef NBDT_KERNEL
+  g_last_igemm = KIND == 0 ? "conv3x3_pp_kernel" : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
   return NBDT_OK;
 }
 
@@ -664,18 +665,18 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.aff_scale = bn ? bn->aff_scale : nullptr; p.aff_shift = bn ? bn->aff_shift : nullptr;
   p.aff_act = bn ? bn->aff_act : 0;
   p.M = M;
-  p.debug = 0;
   const int nt = cout_tile(d->cout);
-  if (hg.nwv == 8) {
-    if (nt == 5) return launch_halo<5, 8>(p, hg, st);
-    if (nt == 4) return launch_halo<4, 8>(p, hg, st);
-    if (nt == 2) return launch_halo<2, 8>(p, hg, st);
-    return launch_halo<1, 8>(p, hg, st);
+#define NBDT_DISPATCH(KIND)                                     \
+  {                                                             \
+    if (nt == 5) return launch_halo<5, KIND>(p, hg, st);        \
+    if (nt == 4) return launch_halo<4, KIND>(p, hg, st);        \
+    if (nt == 2) return launch_halo<2, KIND>(p, hg, st);        \
+    return launch_halo<1, KIND>(p, hg, st);                     \
   }
-  if (nt == 5) return launch_halo<5, 4>(p, hg, st);
-  if (nt == 4) return launch_halo<4, 4>(p, hg, st);
-  if (nt == 2) return launch_halo<2, 4>(p, hg, st);
-  return launch_halo<1, 4>(p, hg, st);
+  if (hg.nwv == 8) NBDT_DISPATCH(0)
+  if (p.w_tiled != nullptr) NBDT_DISPATCH(1)
+  NBDT_DISPATCH(2)
+#undef NBDT_DISPATCH
 }
 
 }  // namespace nbdt

@@ -297,37 +297,6 @@ struct DwGeom {
   int k, stride, pad;
 };
 
-__global__ __launch_bounds__(kThreads) void dw_fwd_kernel(const bf16_t* __restrict__ x,
-                                                          const float* __restrict__ w, DwGeom d, int ppt,
-                                                          bf16_t* __restrict__ y) {
-  const MbGeom& g = d.out;
-  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
-  const int p0 = blockIdx.x * g.PY * ppt + py;
-  for (int q = 0; q < ppt; ++q) {
-    const int p = p0 + q * g.PY;
-    if (p >= g.hw) break;
-    const int ho = (int)fdiv((unsigned)p, g.div_w);
-    const int wo = p - ho * g.W;
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int r = 0; r < d.k; ++r) {
-      const int hi = ho * d.stride + r - d.pad;          // unpadded input row
-      if (hi < -1 || hi > d.Hi) continue;                // outside even the zero border
-      for (int s = 0; s < d.k; ++s) {
-        const int wi = wo * d.stride + s - d.pad;
-        if (wi < -1 || wi > d.Wi) continue;
-        float f[8];
-        unpack8(*(const u32x4_t*)(x + (size_t)b * d.imgi + (hi + 1) * d.rowi + (wi + 1) * g.C + cx * 8), f);
-        const float4 w0 = *(const float4*)(w + (size_t)(r * d.k + s) * g.C + cx * 8);
-        const float4 w1 = *(const float4*)(w + (size_t)(r * d.k + s) * g.C + cx * 8 + 4);
-        acc[0] += f[0] * w0.x; acc[1] += f[1] * w0.y; acc[2] += f[2] * w0.z; acc[3] += f[3] * w0.w;
-        acc[4] += f[4] * w1.x; acc[5] += f[5] * w1.y; acc[6] += f[6] * w1.z; acc[7] += f[7] * w1.w;
-      }
-    }
-    *(u32x4_t*)(y + pix_off(g, b, p, cx)) = pack8(acc);
-  }
-}
 
 // Row-segment form of the depthwise convolution (forward for stride 1|2, and -- with FLIP -- the
 // stride-1 data gradient, which is the same correlation with the kernel rotated by 180 degrees):
@@ -795,12 +764,7 @@ extern "C" int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t
   if (rc) return rc;
   const DwGeom d = dw_geom(B, H, W, C, k, stride, 4);
   hipStream_t st = (hipStream_t)stream;
-  static const bool simple = getenv("NBDT_DW_SIMPLE") != nullptr;   // per-pixel reference kernel (A/B)
-  NBDT_REQUIRE(!(simple && bn_scratch), "fused statistics need the row-segment kernel (unset NBDT_DW_SIMPLE)");
-  if (simple)
-    hipLaunchKernelGGL(dw_fwd_kernel, dim3(d.out.slices, B), dim3(d.out.threads), 0, st, (const bf16_t*)x, w, d, 4,
-                       (bf16_t*)y);
-  else if (k == 3) { if (stride == 1) launch_dw_row<3, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<3, 2, false>(x, w, d, B, y, bn_scratch, st); }
+  if (k == 3) { if (stride == 1) launch_dw_row<3, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<3, 2, false>(x, w, d, B, y, bn_scratch, st); }
   else { if (stride == 1) launch_dw_row<5, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<5, 2, false>(x, w, d, B, y, bn_scratch, st); }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
@@ -813,8 +777,7 @@ extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, i
   if (rc) return rc;
   const MbGeom in = mb_geom(B, H, W, C, 4);
   hipStream_t st = (hipStream_t)stream;
-  static const bool simple = getenv("NBDT_DW_SIMPLE") != nullptr;
-  if (stride == 1 && !simple) {   // same correlation with the kernel rotated by 180 degrees
+  if (stride == 1) {   // same correlation with the kernel rotated by 180 degrees
     const DwGeom d = dw_geom(B, H, W, C, k, 1, 4);
     if (k == 3) launch_dw_row<3, 1, true>(gy, w, d, B, gx, nullptr, st); else launch_dw_row<5, 1, true>(gy, w, d, B, gx, nullptr, st);
   } else {

@@ -259,8 +259,7 @@ static int launch_dma(WgradDmaParams& p, hipStream_t st) {
   const int tiles = d.ntaps * (d.cout / (32 * WM)) * p.n_ci_blocks;
   // 2 resident blocks per CU -> 512 slots per round; pick the split count that fills whole rounds
   // from BELOW (513 items on 512 slots runs two rounds for one block: measured -40%)
-  static const int rounds = getenv("NBDT_WGRAD_ROUNDS") ? atoi(getenv("NBDT_WGRAD_ROUNDS")) : 1;
-  int splits = (512 * rounds) / tiles;
+  int splits = 512 / tiles;
   const int max_splits = p.chunks / 16 > 0 ? p.chunks / 16 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

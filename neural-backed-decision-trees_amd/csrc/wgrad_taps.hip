@@ -41,9 +41,6 @@ struct WgradTapsParams {
 };
 }  // namespace nbdt
 
-#ifndef NBDT_WGT_DEBUG
-#define NBDT_WGT_DEBUG 0   // compile-time timing experiments: 1 no DMA, 2 no waits/barriers, 4 no MFMA/LDS reads
-#endif
 constexpr int KS = 32;
 #ifndef NBDT_WGT_NSTAGE
 #define NBDT_WGT_NSTAGE 3
@@ -108,14 +105,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
   // item order, i.e. co-resident on ONE XCD, so its L2 fetches their common gy / x tiles from HBM once.
   // (split-fastest order spread them over the 8 XCDs: TCC hit rate 27 %, 1.4 GB of HBM reads for 0.36 GB
   // of tensors.)
-#ifdef NBDT_WGT_SPLIT_FASTEST
-  const int split = item % p.splits;
-  const int tile = item / p.splits;
-#else
   const int n_tiles = p.items / p.splits;
   const int tile = item % n_tiles;
   const int split = item / n_tiles;
-#endif
   const int co_blk = tile / p.n_ci_blocks;
   const int ci_blk = tile - co_blk * p.n_ci_blocks;
   const int co0 = co_blk * CG;
@@ -175,13 +167,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
     for (int k = 0; k < IPG; ++k) {
       const int id = wave + NWV * k;
       if (id < G_INSTR)
-        glds16((NBDT_WGT_DEBUG & 16) ? gy_base + (lane << 3) : gsrc + id * 16, __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
+        glds16(gsrc + id * 16, __builtin_amdgcn_readfirstlane(dst0 + id * 1024));
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int id = wave + NWV * k;
-      glds16(x_base + ((NBDT_WGT_DEBUG & 16) ? (lane << 3) : (x_stage + x_lane_src[k])),
-             __builtin_amdgcn_readfirstlane(dst0 + G_BYTES + id * 1024));
+      glds16(x_base + (x_stage + x_lane_src[k]), __builtin_amdgcn_readfirstlane(dst0 + G_BYTES + id * 1024));
     }
   };
 
@@ -233,31 +224,26 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
   };
 
   // ---- pipeline (same protocol as wgrad_dma.hip)
-  constexpr int dbg = NBDT_WGT_DEBUG;
   constexpr int PD = NSTAGE - 1;
-  if (!(dbg & 1)) {
 #pragma unroll
-    for (int i = 0; i < PD; ++i)
-      if (i < n_st) issue(i, s_begin + i);
-  }
+  for (int i = 0; i < PD; ++i)
+    if (i < n_st) issue(i, s_begin + i);
   int slot_i = 0;
   for (int t = 0; t < n_st; ++t) {
-    if (!(dbg & 2)) {
-      // stages t+1 .. t+PD-1 may stay in flight (fewer near the end)
-      int after = n_st - 1 - t;
-      after = after < PD - 1 ? after : PD - 1;
-      if (after >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * MINPW) : "memory");
-      else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    // stages t+1 .. t+PD-1 may stay in flight (fewer near the end)
+    int after = n_st - 1 - t;
+    after = after < PD - 1 ? after : PD - 1;
+    if (after >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * MINPW) : "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MINPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + PD < n_st && !(dbg & 1)) {
+    if (t + PD < n_st) {
       int s2 = slot_i + PD;
       s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
       issue(s2, s_begin + t + PD);
     }
-    if (!(dbg & 4)) compute(slot_i);
+    compute(slot_i);
     slot_i = slot_i + 1 == NSTAGE ? 0 : slot_i + 1;
   }
 
@@ -295,8 +281,7 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   const nbdt_wgrad_desc& d = p.d;
   p.n_ci_blocks = d.cin / (8 * NWV);
   const int tiles = (d.cout / (32 * WM)) * p.n_ci_blocks;
-  static const int rounds = getenv("NBDT_WGRAD_ROUNDS") ? atoi(getenv("NBDT_WGRAD_ROUNDS")) : 1;
-  int splits = ((NWV == 4 ? 512 : 256) * rounds) / tiles;
+  int splits = (NWV == 4 ? 512 : 256) / tiles;
   const int max_splits = p.stages / 16 > 0 ? p.stages / 16 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -334,15 +319,6 @@ int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* d
   p.div_spr = make_fastdiv((unsigned)p.stages_per_row);
   p.div_rg = make_fastdiv((unsigned)p.rowgroups);
   const int mt = d->cout / 32;
-  // 64 cins per block = 28 % fewer DMA bytes per MFMA, but measured 2-6 % SLOWER than two independent
-  // 4-wave blocks per CU (same-box A/B, 320->320 and 640->640): opt-in for experiments only
-  static const bool w8 = getenv("NBDT_WGRAD_W8") != nullptr;
-  if (w8 && d->cin % 64 == 0) {
-    if (mt % 5 == 0) return launch_taps<5, 8>(p, st);
-    if (mt % 4 == 0) return launch_taps<4, 8>(p, st);
-    if (mt % 2 == 0) return launch_taps<2, 8>(p, st);
-    return launch_taps<1, 8>(p, st);
-  }
   if (mt % 5 == 0) return launch_taps<5, 4>(p, st);
   if (mt % 4 == 0) return launch_taps<4, 4>(p, st);
   if (mt % 2 == 0) return launch_taps<2, 4>(p, st);

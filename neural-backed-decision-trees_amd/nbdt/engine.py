@@ -463,12 +463,10 @@ class WRNEngine(_Engine):
         # Weight gradients on a second HIP stream: a wgrad block (55 KB LDS, 4 waves) and a 256-pixel igemm block
         # (76 KB, 4 waves) fit on one CU together, and the two kernels stall on different things, so running
         # conv.wgrad next to the dgrad / BatchNorm-backward chain instead of in front of it is worth 3.9 % of the
-        # step (21.62 -> 20.80 ms, same-box A/B; NBDT_NO_WGRAD_STREAM=1 restores the single-stream order).
-        import os
-        if not os.environ.get("NBDT_NO_WGRAD_STREAM"):
-            self._side = torch.cuda.Stream(device=self.device)
-            for c in self.convs:
-                c.side_stream = self._side
+        # step (21.62 -> 20.80 ms, same-box A/B; engine.set_overlap(False) restores the single-stream order).
+        self._side = torch.cuda.Stream(device=self.device)     # engine.set_overlap(False) puts everything back
+        for c in self.convs:                                   # on the caller's stream (profiling passes)
+            c.side_stream = self._side
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, img, training=None):
@@ -640,11 +638,9 @@ class ResNetEngine(_Engine):
         self.store.add("linear.weight", (num_classes, cin), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.store.add("linear.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.finalize()
-        import os
-        if not os.environ.get("NBDT_NO_WGRAD_STREAM"):     # weight gradients on a second stream (see WRNEngine)
-            self._side = torch.cuda.Stream(device=self.device)
-            for c in self.convs:
-                c.side_stream = self._side
+        self._side = torch.cuda.Stream(device=self.device)     # weight gradients on a second stream (see WRNEngine)
+        for c in self.convs:
+            c.side_stream = self._side
         dev = self.device
         # identity "BN" for the plain average-pool head (features are already post-ReLU)
         self._id_mean = torch.zeros(cin, device=dev)

@@ -145,11 +145,9 @@ class EfficientNetEngine(_Engine):
         self.finalize()
         self._step = 0
         self.dropout_seed = seed
-        import os
-        if not os.environ.get("NBDT_NO_WGRAD_STREAM"):     # weight gradients on a second stream (see WRNEngine)
-            self._side = torch.cuda.Stream(device=self.device)
-            for c in self.convs + self.dws:
-                c.side_stream = self._side
+        self._side = torch.cuda.Stream(device=self.device)     # weight gradients on a second stream (see WRNEngine)
+        for c in self.convs + self.dws:
+            c.side_stream = self._side
 
     # ------------------------------------------------------------------ reference-named views
     def extra_param_views(self, buf):

@@ -8,6 +8,7 @@ DEV = 'cuda:0'
 B = int(os.environ.get('B', 512))
 which = os.environ.get('WHICH', 'wgrad,fwd,dgrad').split(',')
 reps = int(os.environ.get('REPS', 5))
+force = int(os.environ.get('FORCE', 0))   # desc.wide_tile: 2 = 512-pixel ping-pong kernel, 3 = 256-pixel kernels
 shapes = [(32, 160, 160, 3, 1), (16, 320, 320, 3, 1), (8, 640, 640, 3, 1), (32, 160, 320, 3, 2), (32, 32, 160, 3, 1)]
 if os.environ.get('SHAPES'):
     shapes = [shapes[int(i)] for i in os.environ['SHAPES'].split(',')]
@@ -36,10 +37,12 @@ for (H, cin, cout, k, st) in shapes:
     if 'fwd' in which:
         d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
         if wt is not None: d.w_tiled = wt.data_ptr()
+        d.wide_tile = force
         t = timeit(lambda: ops.conv_igemm(d, x, wb, out)); line += f"fwd {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
     if 'epi' in which:
         d = ops.conv_fwd_desc(B, H, H, cin, cout, k, st)
         if wt is not None: d.w_tiled = wt.data_ptr()
+        d.wide_tile = force
         scr = torch.zeros(((B * Ho * Ho + 255) // 256) * 2 * cout, device=DEV)
         res = ops.padded(B, Ho, Ho, cout, DEV); ops.interior(res).normal_()
         fns = [lambda: ops.conv_igemm(d, x, wb, out), lambda: ops.conv_igemm(d, x, wb, out, residual=res),
@@ -53,6 +56,7 @@ for (H, cin, cout, k, st) in shapes:
     if 'dgrad' in which:
         ds = ops.conv_dgrad_descs(B, H, H, cin, cout, k, st)
         if wdt is not None: ds[0].w_tiled = wdt.data_ptr()
+        ds[0].wide_tile = force
         t = timeit(lambda: [ops.conv_igemm(d, g, wd, gx) for d in ds]); line += f"dgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
     if 'wgrad' in which:
         d = ops.conv_wgrad_desc(B, H, H, cin, cout, k, st)

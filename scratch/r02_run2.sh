@@ -10,4 +10,4 @@ done | tee gpurun_out/r02_k2.log
 SHAPES=0 WHICH=fwd timeout 300 bash scratch/ablate.sh pp_noepi pp_noa pp_nodma 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02_abl2.log
 WHICH=epi SHAPES=0,1,2 REPS=10 timeout 300 python scratch/bench_kernels.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02_epi2.log
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --agreement-n 0 2>&1 | tail -1 | tee gpurun_out/r02_b2.log
-NBDT_NO_WGRAD_STREAM=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --agreement-n 0 --no-kernel-timer 2>&1 | tail -1 | tee gpurun_out/r02_b2_nostream.log
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --agreement-n 0 --no-kernel-timer --no-overlap 2>&1 | tail -1 | tee gpurun_out/r02_b2_nostream.log

@@ -426,7 +426,7 @@ def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout):
     ops.conv_igemm(desc(2), xp, wb, out_pp)
     assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
     ops.conv_igemm(desc(3), xp, wb, out_h)
-    assert ops.last_igemm_kernel() == "conv3x3_halo_kernel"
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel/4w"       # same segments, one wave group, 256 pixels
     plain = ops.padded(B, H, W, cout, DEV)       # no tiles: the 256-pixel kernel on the plain weight layout
     ops.conv_igemm(ops.conv_fwd_desc(B, H, W, cin, cout, 3, 1), xp, wb, plain)
     assert ops.last_igemm_kernel() == "conv3x3_halo_kernel" and torch.equal(plain, out_h)
@@ -468,7 +468,7 @@ def test_pingpong_kernel_dgrad_with_bn_backward_epilogue(B, H, W, cin, cout):
     mean, rstd = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
     ops.bn_stats(xp, scratch, mean, rstd)
     outs, sums = [], []
-    for mode, name in ((2, "conv3x3_pp_kernel"), (3, "conv3x3_halo_kernel")):
+    for mode, name in ((2, "conv3x3_pp_kernel"), (3, "conv3x3_pp_kernel/4w")):
         (d,) = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 1)
         _force(d, mode).w_tiled = wdt.data_ptr()
         ga = ops.padded(B, H, W, cin, DEV)

@@ -48,6 +48,7 @@ const char* nbdt_last_error(void);
 /* Name of the device kernel the calling thread's last nbdt_conv_igemm* call launched ("conv3x3_pp_kernel",
  * "conv3x3_halo_kernel", "conv_igemm_dma_kernel"): lets the parity tests assert WHICH kernel they exercised. */
 const char* nbdt_debug_last_igemm(void);
+const char* nbdt_debug_last_wgrad(void);      /* same for nbdt_conv_wgrad */
 int nbdt_version(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int nbdt_device_count(void);
@@ -180,6 +181,8 @@ typedef struct nbdt_wgrad_desc {
   int32_t w_ntaps;
   int32_t x_bs, x_hs, x_ws, x_base;
   int32_t g_bs, g_hs, g_ws, g_base;
+  int32_t variant;              /* dense 3x3 stride-1 launches: 0 = pick from the problem size; 2 = force the 8-wave
+                                   two-pipeline kernel, 3 = force the 4-wave one (tests, A/B measurements) */
 } nbdt_wgrad_desc;
 int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw,
                     void* stream);

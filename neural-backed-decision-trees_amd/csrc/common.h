@@ -128,10 +128,32 @@ struct HaloGeom {
   int nwv;             // waves per block: 4 (256-pixel tile) or 8 (512-pixel tile)
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
+extern thread_local const char* g_last_wgrad;   // ... and the last nbdt_conv_wgrad call
 extern thread_local const char* g_last_igemm;   // name of the kernel the last nbdt_conv_igemm* call launched (tests)
 struct BnBwdArgs;
 int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
                  const void* res, float* stats, const BnBwdArgs* bn, int M, hipStream_t st);
+
+}  // namespace nbdt
+
+// LDS-DMA of 16 B per lane (1 KiB per wave) with the address split as <SGPR base> + <32-bit per-lane byte offset>:
+// the wave-uniform part of the address stays scalar arithmetic and the lane part is one VGPR.  The pad before the
+// load covers "VALU wrote the SGPR (readfirstlane / readlane) -> VMEM reads it as base" (5 wait states; hipcc does
+// not pad inside an asm string).  M0 = LDS destination of lane 0 (the image is lane-linear: lane L lands at +16 L).
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 2\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+namespace nbdt {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 

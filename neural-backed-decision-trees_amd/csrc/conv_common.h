@@ -56,26 +56,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-// Same with the address split as <SGPR base> + <32-bit per-lane byte offset>: the wave-uniform part of the address
-// stays scalar arithmetic and the lane part is one VGPR.  The pad before the load covers "VALU wrote the SGPR
-// (readfirstlane / readlane) -> VMEM reads it as base" (5 wait states; hipcc does not pad inside an asm string).
-__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
-#ifdef NBDT_GLDS_LEAN
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-  return;
-#endif
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 2\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
-}
-
 // ------------------------------------------------------------------------------------------------
 // Epilogue shared by the DMA kernels.  STATS modes (the per-tile partials go to p.stats):
 //   0  none

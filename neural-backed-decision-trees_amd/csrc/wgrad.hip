@@ -30,5 +30,10 @@ extern "C" int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const vo
   const int64_t M_all = (int64_t)d->B * d->gh * d->gw;
   NBDT_REQUIRE(M_all < (1ll << 31), "pixel grid too large");
   if (nbdt::wgrad_taps_applicable(d)) return nbdt::wgrad_taps(d, x, gy, dw, (hipStream_t)stream);
+  NBDT_REQUIRE(d->variant == 0, "variant 2 / 3 select between the dense 3x3 stride-1 kernels only");
+  nbdt::g_last_wgrad = "conv_wgrad_dma_kernel";
   return nbdt::wgrad_dma(d, x, gy, dw, (hipStream_t)stream);
 }
+
+namespace nbdt { thread_local const char* g_last_wgrad = ""; }
+extern "C" const char* nbdt_debug_last_wgrad(void) { return nbdt::g_last_wgrad; }

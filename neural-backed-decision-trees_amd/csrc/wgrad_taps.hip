@@ -15,6 +15,7 @@
 // Partial sums over the pixel splits are combined with fp32 atomics into dw (+= semantics).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace nbdt;
 
@@ -262,26 +263,392 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 8-wave ping-pong form (1 block per CU), built like conv3x3_pp_kernel (conv_halo.hip).  Block tile as above --
+// (32*WM couts) x 32 cins x 9 taps -- but the nine taps are split between two wave groups that work on the SAME
+// LDS stage one barrier apart: waves 0-3 own taps 0-4, waves 4-7 taps 5-8 (inside a group: 2 cout halves x 2 cin
+// halves).  So each stage is loaded once for 8 waves (half the DMA per MFMA of two 4-wave blocks; the 4-wave
+// kernel keeps TA 65 % busy at 42 % MFMA utilisation), a wave holds 100 accumulator registers instead of 180, and
+// its step splits into a load segment (20 transpose reads -> registers, its share of the DMA of stage u+4) and an
+// MFMA segment (25 or 20 MFMAs, plus the address arithmetic of the next load segment in their shadow):
+//     group 0:  bP  L0 b M0 b  L1 b M1 b ...            group 1:  bP b  L0 b M0 b  L1 b M1 ...
+// Stages are 64 pixels (two 32-pixel MFMA K chunks).  Ring of 5 stage slots: stage u+3 is issued in L(u) into the
+// slot stage u-2 left (its last reader, group 1's M(u-2), finished before the barrier in front of group 0's
+// L(u-1)); a wave retires what it issued two load segments ago (vmcnt: one stage's worth may stay in flight)
+// before the barrier that precedes the first read.
+#ifndef NBDT_WPP_TIMING
+#define NBDT_WPP_TIMING 0   // 1: s_memtime stamps around the segments, per-wave sums in g_wpp_timing (scratch/wpp_timing.py)
+#endif
+#if NBDT_WPP_TIMING
+__device__ unsigned g_wpp_timing[2048 * 8];     // [block*8 + wave][8]: load segment, barrier 1, MFMA segment, barrier 2, total, stages
+extern "C" int nbdt_debug_wpp_timing(unsigned* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wpp_timing), sizeof(unsigned) * 2048 * 8);
+}
+__device__ __forceinline__ unsigned wstamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (unsigned)t;
+}
+#define NBDT_WSTAMP(acc_) { const unsigned t_ = wstamp(); acc_ += t_ - tm_prev; tm_prev = t_; }
+#else
+#define NBDT_WSTAMP(acc_)
+#endif
+template <int WM>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsParams p) {
+  constexpr int CG = 32 * WM;
+  constexpr int KSP = 64, KK = KSP / 32;       // pixels per stage: two 32-pixel MFMA K chunks
+  constexpr int PG = 2 * CG;                   // gy row pitch in bytes
+  constexpr int XS = 144;                      // x halo slots per stage (64 B each): 9 pieces
+  constexpr int G_BYTES = KSP * PG;
+  constexpr int X_BYTES = XS * 64;
+  constexpr int STAGE = G_BYTES + X_BYTES;
+  constexpr int G_INSTR = G_BYTES / 1024;      // 4 * WM gy pieces per stage
+  constexpr int X_INSTR = XS / 16;
+  constexpr int IPG = (G_INSTR + 7) / 8;
+  constexpr int NSLOT = 5, PD = 3;
+  constexpr int NT0 = 5;                       // taps of group 0 (group 1: 9 - NT0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const nbdt_wgrad_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
+
+  const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if (item >= p.items) return;
+  const int n_tiles = p.items / p.splits;      // tile fastest: blocks sharing a pixel range sit on one XCD
+  const int tile = item % n_tiles;
+  const int split = item / n_tiles;
+  const int co_blk = tile / p.n_ci_blocks;
+  const int ci_blk = tile - co_blk * p.n_ci_blocks;
+  const int co0 = co_blk * CG;
+  const int ci0 = ci_blk * 32;
+  const int s_begin = split * p.stages_per_split;
+  int s_end = s_begin + p.stages_per_split;
+  s_end = s_end < p.stages ? s_end : p.stages;
+  if (s_begin >= s_end) return;
+  const int n_st = s_end - s_begin;
+
+#define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
+  const int g_bs = NBDT_PIN(d.g_bs), g_hs = NBDT_PIN(d.g_hs), g_ws = NBDT_PIN(d.g_ws);
+  const int x_bs = NBDT_PIN(d.x_bs), x_hs = NBDT_PIN(d.x_hs), x_ws = NBDT_PIN(d.x_ws);
+  const int rs = NBDT_PIN(p.rs), cs = NBDT_PIN(p.cs), hw2 = NBDT_PIN(p.hw2), hp_n = NBDT_PIN(p.hp);
+  FastDiv dspr, drg;
+  dspr.mul = NBDT_PIN(p.div_spr.mul); dspr.sh = NBDT_PIN(p.div_spr.sh); dspr.d = NBDT_PIN(p.div_spr.d);
+  drg.mul = NBDT_PIN(p.div_rg.mul); drg.sh = NBDT_PIN(p.div_rg.sh); drg.d = NBDT_PIN(p.div_rg.d);
+  const unsigned long long gy_u = (unsigned long long)p.gy, x_u = (unsigned long long)p.x;
+  const bf16_t* gy_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(gy_u >> 32)) << 32) |
+                                          (unsigned)NBDT_PIN((unsigned)gy_u));
+  const bf16_t* x_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(x_u >> 32)) << 32) |
+                                         (unsigned)NBDT_PIN((unsigned)x_u));
+#undef NBDT_PIN
+
+  // ---- LDS stage image: PIXEL-MAJOR.  gy [64 px][CG couts] (2*CG-byte rows), x [144 halo slots][32 cins] (64-byte
+  // rows).  The chunk-major image of the 4-wave kernel makes a DMA instruction touch 64 (x) or 32 (gy) cache lines
+  // for its 1 KiB, and the texture path retires ~0.45 lines per clock whatever their payload (probes/dma_probe.hip:
+  // 7.2 and 14.4 B/clk/CU against 52 for contiguous KiB) -- per 32-pixel stage that is 1850 cycles of address
+  // processing for 765 cycles of MFMA: the 4-wave kernel's 42 % MFMA utilisation IS that ratio.  Pixel-major rows
+  // make a gy piece 3.2 whole pixel rows (8-9 lines) and an x piece 16 pixels x 64 B (16 lines).
+  // ds_read_b64_tr_b16 gathers [4 px][16 ch] blocks with a free row stride, so it reads this image directly; the
+  // 32-byte block a 16-lane group reads is XOR-swapped with its neighbour for pixels with bit 2 set (on the DMA
+  // SOURCE address and on the read address), which keeps pixels p and p+4 of one 32-lane pass on different banks.
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned g_voff[IPG];                        // gy pieces {wave + 8k}: piece = LDS bytes [1024 id, +1024)
+#pragma unroll
+  for (int k = 0; k < IPG; ++k) {
+    const int pos = (wave + 8 * k) * 1024 + lane * 16;
+    int px = pos / PG;
+    const int j = (pos - px * PG) >> 4;        // 16-byte chunk of the row this lane fills
+    const int src_chunk = j ^ (((px >> 2) & 1) << 1);
+    px = px < KSP ? px : KSP - 1;              // (ids past the tile are never issued)
+    g_voff[k] = (unsigned)((px / cs) * g_hs + (px % cs) * g_ws + d.g_base + co0 + src_chunk * 8) * 2u;
+  }
+  unsigned x_voff[2];                          // x pieces {wave, 8 (wave 0 only)}: halo slots [16 id, +16) x 64 B
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int slot = 16 * (wave + 8 * k) + (lane >> 2);
+    const int src_chunk = (lane & 3) ^ (((slot >> 2) & 1) << 1);
+    const int hp = slot < hp_n ? slot : hp_n - 1;          // unused slots re-fetch the last halo pixel
+    x_voff[k] = (unsigned)((hp / hw2) * x_hs + (hp % hw2) * x_ws + d.x_base + ci0 + src_chunk * 8) * 2u;
+  }
+  int n_mine = 1 + (wave + 8 < X_INSTR ? 1 : 0);           // DMA instructions this wave issues per stage
+#pragma unroll
+  for (int k = 0; k < IPG; ++k) n_mine += (wave + 8 * k < G_INSTR) ? 1 : 0;
+
+  // stage -> scalar element offsets of its gy / x tiles (image b, first row r0, first col c0)
+  auto stage_off = [&](int stage, int& g_stage, int& x_stage) {
+    const unsigned st = (unsigned)stage;       // (branch-free divisions: a branch would split the MFMA segment)
+    const unsigned q1m = __umulhi(st, dspr.mul) >> dspr.sh;
+    const unsigned q1 = dspr.d == 1 ? st : q1m;
+    const int sc = (int)(st - q1 * dspr.d);
+    const unsigned bm = __umulhi(q1, drg.mul) >> drg.sh;
+    const unsigned b = drg.d == 1 ? q1 : bm;
+    const int rg = (int)(q1 - b * drg.d);
+    const int r0 = rg * rs, c0 = sc * cs;
+    g_stage = (int)b * g_bs + r0 * g_hs + c0 * g_ws;
+    x_stage = (int)b * x_bs + r0 * x_hs + c0 * x_ws;
+  };
+  auto issue = [&](int slot_i, int g_stage, int x_stage) {
+    const unsigned dst0 = lds_base + slot_i * STAGE;
+#pragma unroll
+    for (int k = 0; k < IPG; ++k)
+      if (wave + 8 * k < G_INSTR) glds16_s(gy_base + g_stage, g_voff[k], dst0 + (wave + 8 * k) * 1024);
+    glds16_s(x_base + x_stage, x_voff[0], dst0 + G_BYTES + wave * 1024);
+    if (wave + 8 < X_INSTR) glds16_s(x_base + x_stage, x_voff[1], dst0 + G_BYTES + (wave + 8) * 1024);
+  };
+
+  f32x4 acc[NT0][WM];
+#pragma unroll
+  for (int t = 0; t < NT0; ++t)
+#pragma unroll
+    for (int a = 0; a < WM; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transpose-read addressing: 16-lane group g4 reads pixels 4 g4 .. 4 g4+3 (and +16) of a 32-pixel K chunk,
+  // lane t16 the 8 bytes (4 channels) number t16&3 of pixel 4 g4 + (t16>>2) in a 16-channel block; it ends up with
+  // channel t16.
+  typedef const __attribute__((address_space(3))) unsigned char* lds_cptr;
+  typedef __attribute__((address_space(3))) s16x4* lds_tr;
+  const lds_cptr smem3 = (lds_cptr)smem;
+  const int g4 = lane >> 4, t16 = lane & 15;
+  const int rr = 4 * g4 + (t16 >> 2);
+  const int c8 = (t16 & 3) * 8;
+  // gy: 16-cout block b of pixel px sits at px*PG + (b ^ ((px>>2)&1))*32; (px>>2)&1 == g4&1 for px = rr + 16 j.
+  // Blocks b and b+2 swap the same way: two per-lane bases (tiles a = 0, 1), the rest are +64 B immediates.
+  int g_lane_off[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) g_lane_off[a] = rr * PG + (((wm * WM + a) ^ (g4 & 1)) * 32) + c8;
+  int xpos[KK][2];                             // halo slot of this lane's pixels 32 kk + rr (+16) at tap (0,0)
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = kk * 32 + rr + 16 * h;
+      xpos[kk][h] = (k / cs) * hw2 + (k % cs);
+    }
+  const int x_lane_off = G_BYTES + c8;
+
+  // ---- prologue: stages 0 .. PD-1, all landed before the first load segment
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (u < n_st) {
+      int gs, xs;
+      stage_off(s_begin + u, gs, xs);
+      issue(u, gs, xs);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                // bP
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // One group's main loop; T0 / NTP are literals so every register array is statically indexed.
+  auto run = [&](auto t0_c, auto ntp_c) {
+    constexpr int T0 = decltype(t0_c)::value, NTP = decltype(ntp_c)::value;
+    // x fragment offsets inside a stage slot: per lane, per (K chunk, tap, pixel half) -- stage independent, so
+    // they are computed once; a stage only adds its slot base (one v_add each, in the MFMA segment's shadow)
+    int xrel[KK][NTP][2];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int t = 0; t < NTP; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int toff = ((T0 + t) / 3) * hw2 + ((T0 + t) % 3);
+          const int hs = xpos[kk][h] + toff;               // halo slot; its 32-byte half: wn ^ bit 2 of the slot
+          xrel[kk][t][h] = x_lane_off + ((hs << 6) | ((((hs >> 2) ^ wn) & 1) << 5));
+        }
+    lds_cptr xa[KK][NTP][2];                   // x fragment addresses of the next load segment
+    lds_cptr ga[2];
+    auto prepare = [&](int slot_i) {
+      int off = slot_i * STAGE;
+      asm volatile("" : "+s"(off));            // the adds stay in the segment that calls this
+      const lds_cptr base = smem3 + off;
+      ga[0] = base + g_lane_off[0];
+      ga[1] = base + g_lane_off[1];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+          xa[kk][t][0] = base + xrel[kk][t][0];
+          xa[kk][t][1] = base + xrel[kk][t][1];
+        }
+    };
+    prepare(0);
+    int slot_n = 1 % NSLOT, slot_d = PD % NSLOT;
+    int g_next = 0, x_next = 0;                // tile offsets of stage u + PD, computed in M(u-1)
+    if (PD < n_st) stage_off(s_begin + PD, g_next, x_next);
+#if NBDT_WPP_TIMING
+    unsigned tm_l = 0, tm_b1 = 0, tm_m = 0, tm_b2 = 0;
+    const unsigned tm_begin = wstamp();
+    unsigned tm_prev = tm_begin;
+#endif
+    for (int u = 0; u < n_st; ++u) {
+      // ================= L(u): fragments -> registers, this wave's DMA pieces of stage u + PD =================
+      bf16x8 gf[KK][WM], xf[KK][NTP];
+      auto read_chunk = [&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+          const lds_cptr a0 = ga[a & 1] + ((a >> 1) * 64 + kk * 32 * PG);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 16 * PG));
+          gf[kk][a] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[kk][t][0]);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[kk][t][1]);
+          xf[kk][t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      };
+      // Only the FIRST K chunk's fragments are read here: 8-byte LDS reads reach their rate only with several waves
+      // per SIMD in flight, and a load segment has one -- all 40 reads took ~870 cycles (s_memtime), longer than
+      // the partner's MFMA segment.  The second chunk is read inside the MFMA segment, under the first chunk's MFMAs.
+#if NBDT_WPP_TIMING == 3     // diagnosis only: DMA wait first, so that its stamp does not include the LDS reads
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      NBDT_WSTAMP(tm_m)       // (timing 3: column "mfma-seg" = vmcnt wait alone)
+#endif
+      read_chunk(std::integral_constant<int, 0>{});
+      // stage u+1 (issued two load segments ago) must be in LDS before the next barrier; the stage issued since
+      // may stay in flight.  Near the end nothing was issued: drain.
+      if (u + PD <= n_st) {                    // the previous load segment issued a full stage
+        switch (n_mine) {
+#define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+          NBDT_CASE(1) NBDT_CASE(2) NBDT_CASE(3) NBDT_CASE(4) NBDT_CASE(5)
+#undef NBDT_CASE
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#if NBDT_WPP_TIMING > 1
+      NBDT_WSTAMP(tm_b1)      // (fine timing: column "barrier1" = reads issued + vmcnt wait)
+#endif
+
+      if (u + PD < n_st) issue(slot_d, g_next, x_next);
+#if NBDT_WPP_TIMING > 1
+      NBDT_WSTAMP(tm_b2)      // (fine timing: column "barrier2" = DMA issue)
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      NBDT_WSTAMP(tm_l)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#if NBDT_WPP_TIMING == 1
+      NBDT_WSTAMP(tm_b1)
+#elif NBDT_WPP_TIMING == 3
+      NBDT_WSTAMP(tm_l)
+#else
+      NBDT_WSTAMP(tm_m)
+#endif
+      // ================= M(u): KK * NTP * WM MFMAs; their shadow prepares L(u+1) =================
+      __builtin_amdgcn_s_setprio(1);
+      read_chunk(std::integral_constant<int, 1>{});
+      prepare(slot_n);
+      stage_off(s_begin + u + 1 + PD, g_next, x_next);     // (past the end: computed, never used)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int t = 0; t < NTP; ++t)
+#pragma unroll
+          for (int a = 0; a < WM; ++a)
+            acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kk][a], xf[kk][t], acc[t][a], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < KK * NTP * WM; ++i) {              // one MFMA, one of each other kind in its shadow
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+        __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
+      }
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(xa[kk][t][0]), "+v"(xa[kk][t][1]));
+      asm volatile("" : "+v"(ga[0]), "+v"(ga[1]));
+      __builtin_amdgcn_s_setprio(0);
+      NBDT_WSTAMP(tm_m)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#if NBDT_WPP_TIMING == 1
+      NBDT_WSTAMP(tm_b2)
+#elif NBDT_WPP_TIMING == 3
+      NBDT_WSTAMP(tm_l)
+#else
+      NBDT_WSTAMP(tm_m)
+#endif
+      slot_n = slot_n + 1 == NSLOT ? 0 : slot_n + 1;
+      slot_d = slot_d + 1 == NSLOT ? 0 : slot_d + 1;
+    }
+#if NBDT_WPP_TIMING
+    if (lane == 0 && item < 256) {
+      unsigned* o = g_wpp_timing + (item * 8 + wave) * 8;
+      o[0] = tm_l; o[1] = tm_b1; o[2] = tm_m; o[3] = tm_b2; o[4] = tm_prev - tm_begin; o[5] = n_st;
+    }
+#endif
+    // ---- epilogue: acc[t][a][r]: co = co0 + (wm*WM + a)*16 + 4*g4 + r ; ci = ci0 + wn*16 + t16
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    const int ci = ci0 + wn * 16 + t16;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+      const int w_tap = d.w_tap[T0 + t];
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
+          atomicAdd(p.dw + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
+        }
+    }
+  };
+  if (grp == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
+  else run(std::integral_constant<int, NT0>{}, std::integral_constant<int, 9 - NT0>{});
+}
+
 namespace nbdt {
+
+static bool stage_geometry(const nbdt_wgrad_desc* d, int ks, int max_hp, WgradTapsParams* p);
 
 bool wgrad_taps_applicable(const nbdt_wgrad_desc* d) {
   if (d->ntaps != 9 || d->x_base != 0) return false;
   if (d->x_ws != d->cin || d->x_hs != (d->gw + 2) * d->cin || d->x_bs != (d->gh + 2) * d->x_hs) return false;
   for (int t = 0; t < 9; ++t)
     if (d->tap_off[t] != (t / 3) * d->x_hs + (t % 3) * d->x_ws) return false;
+  return stage_geometry(d, 32, 128, nullptr);
+}
+
+// Stage rectangle (rs x cs pixels of one image) and halo for stages of `ks` pixels; false when they do not tile it.
+static bool stage_geometry(const nbdt_wgrad_desc* d, int ks, int max_hp, WgradTapsParams* p) {
   const int gw = d->gw, gh = d->gh;
-  if (!(gw % 32 == 0 || 32 % gw == 0)) return false;
-  const int rs = gw >= 32 ? 1 : 32 / gw;
+  if (!(gw % ks == 0 || ks % gw == 0)) return false;
+  const int rs = gw >= ks ? 1 : ks / gw;
   if (gh % rs != 0) return false;
+  const int cs = gw >= ks ? ks : gw;
+  if ((rs + 2) * (cs + 2) > max_hp) return false;
+  const long long M = (long long)d->B * gh * gw;
+  if (!p) return true;
+  p->stages = (int)(M / ks);
+  p->rs = rs; p->cs = cs;
+  p->hw2 = cs + 2;
+  p->hp = (rs + 2) * (cs + 2);
+  p->stages_per_row = gw / cs;
+  p->rowgroups = gh / rs;
+  p->div_spr = make_fastdiv((unsigned)p->stages_per_row);
+  p->div_rg = make_fastdiv((unsigned)p->rowgroups);
   return true;
 }
 
-template <int WM, int NWV>
+// PP: the 8-wave ping-pong kernel, 64-pixel stages, 1 block per CU (256 block slots); else 4-wave blocks,
+// 32-pixel stages, 2 per CU (512 slots)
+template <int WM, bool PP>
 static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   const nbdt_wgrad_desc& d = p.d;
-  p.n_ci_blocks = d.cin / (8 * NWV);
+  p.n_ci_blocks = d.cin / 32;
   const int tiles = (d.cout / (32 * WM)) * p.n_ci_blocks;
-  int splits = (NWV == 4 ? 512 : 256) / tiles;
+  // the split count fills whole rounds of resident blocks from BELOW (513 items on 512 slots cost 40 %)
+  int splits = (PP ? 256 : 512) / tiles;
   const int max_splits = p.stages / 16 > 0 ? p.stages / 16 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -290,15 +657,17 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   p.splits = splits;
   p.items = tiles * splits;
   p.per_xcd = (p.items + 7) / 8;
-  const size_t shmem = (size_t)NSTAGE * ((32 * WM / 8) * 512 + x_bytes(NWV));
+  const size_t shmem = PP ? (size_t)5 * (64 * 64 * WM + 144 * 64) : (size_t)NSTAGE * ((32 * WM / 8) * 512 + x_bytes(4));
+  const void* fn = PP ? reinterpret_cast<const void*>(&conv_wgrad_pp_kernel<WM>)
+                      : reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, 4>);
   static bool attr_set = false;
   if (!attr_set) {
-    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, NWV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    NBDT_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_taps_kernel<WM, NWV>), dim3(p.per_xcd * 8), dim3(64 * NWV), shmem, st, p);
-  NBDT_LAUNCH_CHECK();
+  void* args[] = {(void*)&p};
+  NBDT_HIP_CHECK(hipLaunchKernel(fn, dim3(p.per_xcd * 8), dim3(PP ? 512 : 256), args, shmem, st));
+  g_last_wgrad = PP ? "conv_wgrad_pp_kernel" : "conv_wgrad_taps_kernel";
   return NBDT_OK;
 }
 
@@ -308,21 +677,26 @@ int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* d
   p.x = (const bf16_t*)x;
   p.gy = (const bf16_t*)gy;
   p.dw = dw;
-  const int M = d->B * d->gh * d->gw;
-  p.stages = M / KS;
-  p.rs = d->gw >= 32 ? 1 : 32 / d->gw;
-  p.cs = d->gw >= 32 ? 32 : d->gw;
-  p.hw2 = p.cs + 2;
-  p.hp = (p.rs + 2) * (p.cs + 2);
-  p.stages_per_row = d->gw / p.cs;
-  p.rowgroups = d->gh / p.rs;
-  p.div_spr = make_fastdiv((unsigned)p.stages_per_row);
-  p.div_rg = make_fastdiv((unsigned)p.rowgroups);
   const int mt = d->cout / 32;
-  if (mt % 5 == 0) return launch_taps<5, 4>(p, st);
-  if (mt % 4 == 0) return launch_taps<4, 4>(p, st);
-  if (mt % 2 == 0) return launch_taps<2, 4>(p, st);
-  return launch_taps<1, 4>(p, st);
+  // the 8-wave kernel: 64-pixel stages must tile the images (halo <= 144 slots) and a block needs a few dozen of
+  // them to amortise its prologue; the 32-bit lane offsets of its DMA need tensors below 4 GiB
+  const long long M = (long long)d->B * d->gh * d->gw;
+  const bool pp_fits = stage_geometry(d, 64, 144, nullptr) && (long long)d->B * d->x_bs * 2 < (1ll << 32) &&
+                       (long long)d->B * d->g_bs * 2 < (1ll << 32);
+  NBDT_REQUIRE(!(d->variant == 2 && !pp_fits), "variant 2 (8-wave weight-gradient kernel): shape does not fit it");
+  const bool pp = pp_fits && (d->variant == 2 || (d->variant != 3 && M / 64 >= 32 * 8));
+  if (pp) {
+    stage_geometry(d, 64, 144, &p);
+    if (mt % 5 == 0) return launch_taps<5, true>(p, st);
+    if (mt % 4 == 0) return launch_taps<4, true>(p, st);
+    if (mt % 2 == 0) return launch_taps<2, true>(p, st);
+    return launch_taps<1, true>(p, st);
+  }
+  stage_geometry(d, 32, 128, &p);
+  if (mt % 5 == 0) return launch_taps<5, false>(p, st);
+  if (mt % 4 == 0) return launch_taps<4, false>(p, st);
+  if (mt % 2 == 0) return launch_taps<2, false>(p, st);
+  return launch_taps<1, false>(p, st);
 }
 
 }  // namespace nbdt

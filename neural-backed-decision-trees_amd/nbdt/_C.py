@@ -46,6 +46,7 @@ class WgradDesc(ctypes.Structure):
         ("tap_off", c_int32 * 9), ("w_tap", c_int32 * 9), ("w_ntaps", c_int32),
         ("x_bs", c_int32), ("x_hs", c_int32), ("x_ws", c_int32), ("x_base", c_int32),
         ("g_bs", c_int32), ("g_hs", c_int32), ("g_ws", c_int32), ("g_base", c_int32),
+        ("variant", c_int32),
     ]
 
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "nbdt_tree_destroy": (c_int, [c_void_p]),
     "nbdt_tree_max_depth": (c_int, [c_void_p]),
     "nbdt_debug_last_igemm": (c_char_p, []),
+    "nbdt_debug_last_wgrad": (c_char_p, []),
     "nbdt_soft_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P]),
     "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,

@@ -269,6 +269,10 @@ def last_igemm_kernel():
     return lib().nbdt_debug_last_igemm().decode()
 
 
+def last_wgrad_kernel():
+    return lib().nbdt_debug_last_wgrad().decode()
+
+
 def weight_prep_batched(flat, table, n_layers, total, wd_flat):
     check(lib().nbdt_weight_prep_batched(ptr(flat), ptr(table), n_layers, total, ptr(wd_flat),
                                          stream_ptr(flat.device)))

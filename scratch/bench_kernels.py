@@ -60,5 +60,6 @@ for (H, cin, cout, k, st) in shapes:
         t = timeit(lambda: [ops.conv_igemm(d, g, wd, gx) for d in ds]); line += f"dgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF  "
     if 'wgrad' in which:
         d = ops.conv_wgrad_desc(B, H, H, cin, cout, k, st)
+        if k == 3 and st == 1: d.variant = int(os.environ.get('VARIANT', 0))
         t = timeit(lambda: ops.conv_wgrad(d, x, g, dw)); line += f"wgrad {t*1e6:.0f}us {flops/t/1e12:.0f}TF"
     print(line, flush=True)

@@ -559,5 +559,30 @@ def test_bench_shape_conv_forward_dgrad_wgrad(B, H, W, C):
     # weight gradient (all-taps kernel at its production tile count)
     dw = torch.zeros(C, 9, C, dtype=torch.float32, device=DEV)
     ops.conv_wgrad(ops.conv_wgrad_desc(B, H, W, C, C, 3, 1), xp, gp, dw)
+    assert ops.last_wgrad_kernel() == "conv_wgrad_pp_kernel"
     gw_ref = wref.grad.permute(0, 2, 3, 1).reshape(C, 9, C)
     np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), rtol=2e-3, atol=2e-3 * gw_ref.abs().mean().item())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 32, 32, 32, 160), (3, 16, 16, 64, 64), (9, 8, 8, 160, 320),
+                                            (1, 32, 32, 96, 32), (5, 16, 16, 160, 160), (1, 8, 8, 64, 128)])
+def test_weight_gradient_kernel_variants(B, H, W, cin, cout):
+    """The 8-wave two-pipeline weight-gradient kernel (variant 2: two wave groups on stages of opposite parity, odd
+    and tiny stage counts included) and the 4-wave kernel (variant 3) against fp32 PyTorch on the same bf16 inputs,
+    with += semantics."""
+    xf, xp = _rand_act(B, H, W, cin, seed=91)
+    gf, gp = _rand_act(B, H, W, cout, seed=92)
+    xt = xf.permute(0, 3, 1, 2)
+    wref = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(xt, wref, padding=1).backward(gf.permute(0, 3, 1, 2))
+    gw_ref = wref.grad.permute(0, 2, 3, 1).reshape(cout, 9, cin)
+    tol = dict(rtol=2e-3, atol=2e-3 * gw_ref.abs().mean().item())
+    for variant, name in ((2, "conv_wgrad_pp_kernel"), (3, "conv_wgrad_taps_kernel")):
+        d = ops.conv_wgrad_desc(B, H, W, cin, cout, 3, 1)
+        d.variant = variant
+        dw = torch.zeros(cout, 9, cin, dtype=torch.float32, device=DEV)
+        ops.conv_wgrad(d, xp, gp, dw)
+        assert ops.last_wgrad_kernel() == name
+        np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), **tol)
+        ops.conv_wgrad(d, xp, gp, dw)
+        np.testing.assert_allclose(dw.cpu().numpy(), 2 * gw_ref.numpy(), rtol=2e-3, atol=2 * tol["atol"])

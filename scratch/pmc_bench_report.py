@@ -38,8 +38,11 @@ with open(prefix + "_pmc.txt", "w") as fo:
         fo.write(f"{k}   (n={len(a['SQ_WAVE_CYCLES'])} launches, avg {dur.get(k, 0):.1f} us)\n")
         if gui > 0:
             mf = mean(a["SQ_VALU_MFMA_BUSY_CYCLES"])
-            fo.write(f"    elapsed {gui:10.0f} cycles  -> {gui / max(dur.get(k, 1e9), 1e-9) / 1e3:5.2f} GHz   "
-                     f"MFMA utilisation {mf / (1024 * gui):6.1%}   (SQ_VALU_MFMA_BUSY_CYCLES {mf:.4g})\n")
+            if mf > 0:
+                fo.write(f"    elapsed {gui:10.0f} shader cycles (~{gui / max(dur.get(k, 1e9), 1e-9) / 1e3:4.2f} GHz against the trace pass's "
+                         f"duration; different runs)   MFMA utilisation {mf / (1024 * gui):6.1%}   (SQ_VALU_MFMA_BUSY_CYCLES {mf:.4g})\n")
+            else:
+                fo.write(f"    elapsed {gui:10.0f} shader cycles\n")
         if wc > 0:
             fo.write("    wave time: " + "  ".join(
                 f"{n} {mean(a[n]) / wc:6.1%}" for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS")) + "\n")

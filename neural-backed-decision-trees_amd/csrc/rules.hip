@@ -19,6 +19,9 @@
 // Compiled with -ffp-contract=off and correctly rounded division.
 #include "common.h"
 
+#include <algorithm>
+#include <vector>
+
 namespace nbdt {
 thread_local char g_err[512] = "";
 }
@@ -28,20 +31,26 @@ using namespace nbdt;
 struct nbdt_tree {
   int device;
   int C, N, R, L, root, max_depth;
+  int sched_len;   // rows * lanes-per-sample of the slot schedule (see build_slot_schedule)
   int32_t* d_all;  // one allocation
   const int32_t *node_off, *slot_off, *slot_cls, *cls_off, *cls_slot, *slot_next;
+  const int32_t* sched;  // [3][sched_len]: slot id (or -1), first and one-past-last element in slot_cls
 };
 
 struct TreeView {
-  int C, N, R, root, max_depth;
-  const int32_t *node_off, *slot_off, *slot_cls, *cls_off, *cls_slot, *slot_next;
+  int C, N, R, L, root, max_depth, sched_len;
+  int tl_ints;  // LDS ints in front of the sample rows: the offset arrays (stage_tree), set per launch
+  int staged;  // the per-sample LDS row ends in an L-float staging area (set per launch, see rules_lds_floats)
+  const int32_t *node_off, *slot_off, *slot_cls, *cls_off, *cls_slot, *slot_next, *sched;
 };
 
 static TreeView view_of(const nbdt_tree* t) {
   TreeView v;
-  v.C = t->C; v.N = t->N; v.R = t->R; v.root = t->root; v.max_depth = t->max_depth;
+  v.C = t->C; v.N = t->N; v.R = t->R; v.L = t->L; v.root = t->root; v.max_depth = t->max_depth;
+  v.staged = 0; v.tl_ints = 0;
   v.node_off = t->node_off; v.slot_off = t->slot_off; v.slot_cls = t->slot_cls;
   v.cls_off = t->cls_off; v.cls_slot = t->cls_slot; v.slot_next = t->slot_next;
+  v.sched = t->sched; v.sched_len = t->sched_len;
   return v;
 }
 
@@ -53,6 +62,12 @@ struct LoadBF16 { static __device__ __forceinline__ float at(const void* p, int6
 struct LoadF16 { static __device__ __forceinline__ float at(const void* p, int64_t i) { return __half2float(((const __half*)p)[i]); } };
 
 constexpr int kBlock = 256;
+// threads per block of the per-sample kernels: a sample's group of TPS lanes is 1, 4 or 16 waves
+constexpr int block_of(int tps) { return tps > kBlock ? tps : kBlock; }
+
+#ifndef NBDT_RULES_TIMING
+#define NBDT_RULES_TIMING 0   // 1: s_memtime phase stamps in soft_fwd_kernel (scratch/rules_timing.py); outputs are overwritten
+#endif
 
 template <int TPS>
 __device__ __forceinline__ float group_max(float v, float* red, int g_tid) {
@@ -86,30 +101,272 @@ __device__ __forceinline__ float group_sum(float v, float* red, int g_tid) {
   return v;
 }
 
-// phase 0+1: logits row -> LDS, then child logits (nbdt/model.py:94-99)
-template <int TPS, typename LD>
-__device__ __forceinline__ void load_and_node_logits(const TreeView& t, const void* z, int64_t row_off,
-                                                     bool active, int g_tid, float* zs, float* ss) {
+// The three offset arrays (and, for the hard walk, slot -> next node) are read by every phase; each read from
+// global memory is an L2 round trip in front of a dependent chain, so the block copies them to the front of its
+// LDS once, under the latency of the logits load.  The caller's first __syncthreads() publishes them.
+typedef const __attribute__((address_space(3))) int32_t* lds_iptr;
+struct TreeLds { lds_iptr node_off, slot_off, cls_off, sched, slot_next; };
+
+static int tree_lds_ints(const nbdt_tree* t, bool next) {
+  return ((t->N + 1) + (t->R + 1) + (t->C + 1) + 3 * t->sched_len + (next ? t->R : 0) + 3) & ~3;
+}
+
+template <bool NEXT>
+__device__ __forceinline__ TreeLds stage_tree(const TreeView& t, float* lds) {
+  int32_t* d0 = (int32_t*)lds;
+  int32_t* d1 = d0 + (t.N + 1);
+  int32_t* d2 = d1 + (t.R + 1);
+  int32_t* d3 = d2 + (t.C + 1);
+  int32_t* d4 = d3 + 3 * t.sched_len;
+  for (int i = threadIdx.x; i <= t.N; i += (int)blockDim.x) d0[i] = t.node_off[i];
+  for (int i = threadIdx.x; i <= t.R; i += (int)blockDim.x) d1[i] = t.slot_off[i];
+  for (int i = threadIdx.x; i <= t.C; i += (int)blockDim.x) d2[i] = t.cls_off[i];
+  for (int i = threadIdx.x; i < 3 * t.sched_len; i += (int)blockDim.x) d3[i] = t.sched[i];
+  if (NEXT)
+    for (int i = threadIdx.x; i < t.R; i += (int)blockDim.x) d4[i] = t.slot_next[i];
+  TreeLds o;
+  o.node_off = (lds_iptr)d0; o.slot_off = (lds_iptr)d1; o.cls_off = (lds_iptr)d2; o.sched = (lds_iptr)d3;
+  o.slot_next = (lds_iptr)d4;
+  return o;
+}
+
+// The two CSR maps are walked in both directions by ordered fp32 chains (a child's leaves in ascending class
+// order, a class's path in root-to-leaf order).  The order is the arithmetic contract, so a chain cannot be
+// split; what can be taken off it is the indirection.  Gather spreads `stage[j] = src[idx[j]]` over all
+// lanes of the group (coalesced index reads, independent LDS gathers); the chain that follows then walks
+// contiguous LDS with its loads running one block of 8 ahead of the adds, which costs ~8 cycles per element
+// instead of a dependent global-index + LDS round trip (ImageNet-1000: root children are 525 leaves long).
+template <int TPS>
+struct Gather {
+  // Lane g_tid owns elements g_tid + k*TPS of `stage[j] = src[idx[j]]`.  The index reads are L2 round trips, so
+  // issue() puts the first 3*U of them in flight (the ragged last round with clamped addresses, rounds 0 and 1)
+  // and is called a phase early; finish() does the LDS gather/scatter, loading round r+2 while round r runs.
+  static constexpr int U = TPS > 256 ? 4 : 8, S = U * TPS;  // a lane holds ~10 elements (pick_tps): all in flight
+  int ir[U], ia[U], ib[U];
+  int nr, left;
+  const int32_t* ip;
+
+  __device__ __forceinline__ void issue(const int32_t* __restrict__ idx, int L, bool active, int g_tid) {
+    nr = 0;
+    left = 0;
+    ip = idx + g_tid;
+    if (!active) return;
+    const int cnt = (L > g_tid) ? (L - g_tid + TPS - 1) / TPS : 0;
+    nr = cnt / U;
+    left = cnt - nr * U;
+    if (left > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ir[u] = ip[nr * S + min(u, left - 1) * TPS];
+    }
+    if (nr > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ia[u] = ip[u * TPS];
+    }
+    if (nr > 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ib[u] = ip[S + u * TPS];
+    }
+  }
+
+  __device__ __forceinline__ void finish(const float* __restrict__ src, float* __restrict__ stage, int g_tid) {
+    float* sp = stage + g_tid;
+    float x[U];
+    int r = 0;
+    for (; r + 2 <= nr; r += 2) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = src[ia[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) sp[r * S + u * TPS] = x[u];
+      const int ra = min(r + 2, nr - 1);  // past the end: reload the last round, never used
+#pragma unroll
+      for (int u = 0; u < U; ++u) ia[u] = ip[ra * S + u * TPS];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = src[ib[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) sp[(r + 1) * S + u * TPS] = x[u];
+      const int rb = min(r + 3, nr - 1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) ib[u] = ip[rb * S + u * TPS];
+    }
+    if (r < nr) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = src[ia[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) sp[r * S + u * TPS] = x[u];
+    }
+    if (left > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = src[ir[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (u < left) sp[nr * S + u * TPS] = x[u];
+    }
+    __syncthreads();
+  }
+};
+
+struct ChainAdd { static __device__ __forceinline__ float ap(float a, float x) { return a + x; } };
+struct ChainMul { static __device__ __forceinline__ float ap(float a, float x) { return a * x; } };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f32x4* lds_v4ptr;
+
+template <typename OP>
+__device__ __forceinline__ float fold4(float acc, f32x4 x) {
+  acc = OP::ap(acc, x.x);
+  acc = OP::ap(acc, x.y);
+  acc = OP::ap(acc, x.z);
+  return OP::ap(acc, x.w);
+}
+
+// The leading whole blocks of 16 of one chain of n >= 16 elements, acc = OP(...OP(OP(acc, v[0]), v[1])...): up to
+// 3 elements bring the address to 16 bytes, then 32 elements per trip as eight ds_read_b128 issued together
+// and folded as they arrive -- one exposed LDS round trip per 32 dependent operations (element-wise reads cost
+// one per 8: 17 cycles per element on the 525-leaf root children).  Returns the number of elements folded.
+// (A register-rotating version with hand-counted lgkmcnt was faster still but not safe: the compiler copies
+// asm outputs at loop edges, before the data has arrived.)
+template <typename OP>
+__device__ __forceinline__ int long_chain(const float* v, int n, float& acc_io) {
+  float acc = acc_io;
+  const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)v;
+  const int peel = (4 - ((a >> 2) & 3)) & 3;
+  {
+    const float x0 = v[0], x1 = v[1], x2 = v[2];
+    acc = (0 < peel) ? OP::ap(acc, x0) : acc;
+    acc = (1 < peel) ? OP::ap(acc, x1) : acc;
+    acc = (2 < peel) ? OP::ap(acc, x2) : acc;
+  }
+  lds_v4ptr p = (lds_v4ptr)(size_t)(a + 4 * peel);
+  int rem = n - peel;  // >= 13
+  for (; rem >= 32; rem -= 32, p += 8) {
+    f32x4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = p[u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fold4<OP>(acc, x[u]);
+  }
+  if (rem >= 16) {
+    f32x4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = p[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fold4<OP>(acc, x[u]);
+    rem -= 16;
+  }
+  acc_io = acc;
+  return n - rem;
+}
+
+// acc[m] = OP(...OP(OP(acc[m], v[b[m]]), v[b[m]+1])..., v[e[m]-1]) in exactly that order, for the M independent
+// chains one lane holds (an empty chain, b == e, leaves acc alone).  Chains of 16 or more first go through
+// long_chain one after the other (the schedule puts the few there are in the first pass of one wave).  The
+// last 0..15 elements of every chain are folded jointly: whole blocks of 4 are read (up to 3 floats past e) and
+// folded under a per-element select; a block no lane of the wave needs is skipped, and the M chains share each
+// LDS round trip.
+template <typename OP, int M>
+__device__ __forceinline__ void chains(const float* v, const int (&b)[M], const int (&e)[M], float (&acc)[M]) {
+  int j[M], n[M];
+  int most = 0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    j[m] = b[m];
+    n[m] = e[m] - b[m];
+    if (n[m] >= 16) {
+      const int done = long_chain<OP>(v + b[m], n[m], acc[m]);
+      j[m] += done;
+      n[m] -= done;
+    }
+    most = max(most, n[m]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (__ballot(most > 4 * q) == 0) break;
+    float x[M][4];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[m][u] = v[j[m] + 4 * q + u];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (M > 1 && __ballot(n[m] > 4 * q) == 0) continue;  // e.g. the rows past a wave's last chunk
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[m] = (4 * q + u < n[m]) ? OP::ap(acc[m], x[m][u]) : acc[m];
+    }
+  }
+}
+
+// chains one lane folds per pass.  A 4-wave group leaves one wave per SIMD, so a lane folds its two slots (or
+// classes) together; a 16-wave group has other waves to hide the round trips, and 128 VGPRs per lane.
+template <int TPS> constexpr int joint_of() { return TPS == 256 ? 2 : 1; }
+
+// out[s] = ordered sum over the leaves of slot s of src[class] (divided by the leaf count when MEAN)
+template <int TPS, bool MEAN>
+__device__ __forceinline__ void slot_sums(const TreeView& t, const TreeLds& o, const float* src, float* stage, float* out,
+                                          bool active, int g_tid, Gather<TPS>& g, Gather<TPS>& gn,
+                                          const int32_t* next_idx) {
+  // g's indices were issued a phase ago; the next gather's are issued here, ahead of the chains
+  if (t.staged) {
+    g.finish(src, stage, g_tid);
+    if (next_idx) gn.issue(next_idx, t.L, active, g_tid);
+  }
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) zs[c] = LD::at(z, row_off + c);
-  __syncthreads();
-  if (active)
-    for (int s = g_tid; s < t.R; s += TPS) {
-      const int b = t.slot_off[s], e = t.slot_off[s + 1];
-      float acc = 0.f;
-      for (int j = b; j < e; ++j) acc = acc + zs[t.slot_cls[j]];
-      ss[s] = acc / (float)(e - b);
+    for (int k = g_tid; k < t.sched_len; k += joint_of<TPS>() * TPS) {
+      int s[joint_of<TPS>()], b[joint_of<TPS>()], e[joint_of<TPS>()];
+      float acc[joint_of<TPS>()];
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m) {
+        const int km = k + m * TPS;
+        const bool in = km < t.sched_len;
+        s[m] = in ? o.sched[km] : -1;  // -1 also pads the rows of a wave that has run out of slots
+        b[m] = in ? o.sched[t.sched_len + km] : 0;
+        e[m] = in ? o.sched[2 * t.sched_len + km] : 0;
+        if (s[m] < 0) b[m] = e[m] = 0;
+        acc[m] = 0.f;
+      }
+      if (t.staged) {
+        chains<ChainAdd, joint_of<TPS>()>(stage, b, e, acc);
+      } else {
+#pragma unroll
+        for (int m = 0; m < joint_of<TPS>(); ++m)
+          for (int j = b[m]; j < e[m]; ++j) acc[m] = acc[m] + src[t.slot_cls[j]];
+      }
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (s[m] >= 0) out[s[m]] = MEAN ? acc[m] / (float)(e[m] - b[m]) : acc[m];
     }
   __syncthreads();
 }
 
+// phase 0+1: logits row -> LDS, then child logits (nbdt/model.py:94-99)
+template <int TPS, typename LD>
+__device__ __forceinline__ void load_and_node_logits(const TreeView& t, const TreeLds& o, const void* z, int64_t row_off,
+                                                     bool active, int g_tid, float* zs, float* ss,
+                                                     float* stage, Gather<TPS>& g, Gather<TPS>& gn,
+                                                     const int32_t* next_idx) {
+  if (active)
+    for (int c = g_tid; c < t.C; c += TPS) zs[c] = LD::at(z, row_off + c);
+  __syncthreads();
+  slot_sums<TPS, true>(t, o, zs, stage, ss, active, g_tid, g, gn, next_idx);
+}
+
 // phase 2: per-node softmax (nbdt/model.py:114)
 template <int TPS>
-__device__ __forceinline__ void node_softmax(const TreeView& t, bool active, int g_tid, const float* ss,
+__device__ __forceinline__ void node_softmax(const TreeView& t, const TreeLds& o, bool active, int g_tid, const float* ss,
                                              float* ps) {
   if (active)
     for (int n = g_tid; n < t.N; n += TPS) {
-      const int b = t.node_off[n], e = t.node_off[n + 1];
+      const int b = o.node_off[n], e = o.node_off[n + 1];
+      if (e - b == 2) {  // binary node (every induced hierarchy): same operations, one LDS round trip
+        const float s0 = ss[b], s1 = ss[b + 1];
+        const float m = fmaxf(s0, s1);
+        const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+        float sum = 0.f;
+        sum = sum + e0;
+        sum = sum + e1;
+        ps[b] = e0 / sum;
+        ps[b + 1] = e1 / sum;
+        continue;
+      }
       float m = ss[b];
       for (int s = b + 1; s < e; ++s) m = fmaxf(m, ss[s]);
       float sum = 0.f;
@@ -123,11 +380,35 @@ __device__ __forceinline__ void node_softmax(const TreeView& t, bool active, int
   __syncthreads();
 }
 
-__device__ __forceinline__ float path_product(const TreeView& t, int c, const float* ps) {
-  float p = 1.0f;
-  const int b = t.cls_off[c], e = t.cls_off[c + 1];
-  for (int j = b; j < e; ++j) p = p * ps[t.cls_slot[j]];
-  return p;
+// per-slot values along every class's path, staged for class_chain (no-op when the row has no stage)
+template <int TPS>
+__device__ __forceinline__ void stage_paths(const TreeView& t, const float* per_slot, float* stage, int g_tid,
+                                            Gather<TPS>& g) {
+  if (t.staged) g.finish(per_slot, stage, g_tid);
+}
+
+// ordered chains over the slots on the paths of classes c0, c0+TPS, ... (joint_of<TPS>() of them, `init` where the class
+// index runs past C): path products (OP = mul, init 1) of the child probabilities (nbdt/model.py:230-240), or
+// sums (OP = add, init 0) of per-slot gradient terms
+template <int TPS, typename OP>
+__device__ __forceinline__ void class_chains(const TreeView& t, const TreeLds& o, int c0, const float* per_slot,
+                                             const float* stage, float init, float (&acc)[joint_of<TPS>()]) {
+  int b[joint_of<TPS>()], e[joint_of<TPS>()];
+#pragma unroll
+  for (int m = 0; m < joint_of<TPS>(); ++m) {
+    const int c = c0 + m * TPS;
+    const bool in = c < t.C;
+    b[m] = in ? o.cls_off[c] : 0;
+    e[m] = in ? o.cls_off[c + 1] : 0;
+    acc[m] = init;
+  }
+  if (t.staged) {
+    chains<OP, joint_of<TPS>()>(stage, b, e, acc);
+  } else {
+#pragma unroll
+    for (int m = 0; m < joint_of<TPS>(); ++m)
+      for (int j = b[m]; j < e[m]; ++j) acc[m] = OP::ap(acc[m], per_slot[t.cls_slot[j]]);
+  }
 }
 
 // Categorical(probs=p).entropy() for one node (probs renormalised, log clamped to [eps, 1-eps])
@@ -148,47 +429,116 @@ __device__ __forceinline__ float node_entropy(const float* ps, int b, int e) {
 // kernels: grid = ceil(B / SPB) blocks of 256 threads, SPB = 256 / TPS samples per block
 
 template <int TPS, typename LD>
-__global__ __launch_bounds__(kBlock) void soft_fwd_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+__global__ __launch_bounds__(block_of(TPS)) void soft_fwd_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
                                                           float* __restrict__ P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = kBlock / TPS;
+  constexpr int SPB = block_of(TPS) / TPS;
   const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
   const int64_t sample = (int64_t)blockIdx.x * SPB + g;
   const bool active = sample < B;
-  const int stride = t.C + 2 * t.R;
-  float* zs = lds + (size_t)g * stride;
+  const int stride = t.C + 2 * t.R + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
   float* ss = zs + t.C;
   float* ps = ss + t.R;
-  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
-  node_softmax<TPS>(t, active, g_tid, ss, ps);
+  float* stage = ps + t.R;
+#if NBDT_RULES_TIMING
+  // phase stamps of block 0, one row of 8 per wave, written over P[0, :32] (scratch/rules_timing.py)
+  unsigned tsv[8];
+#define NBDT_RSTAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tsv[i] = (unsigned)t_; }
+  NBDT_RSTAMP(0)
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) P[sample * t.C + c] = path_product(t, c, ps);
+    for (int c = g_tid; c < t.C; c += TPS) zs[c] = LD::at(z, sample * ldz + c);
+  __syncthreads();
+  NBDT_RSTAMP(1)
+  if (t.staged) {
+    ga.finish(zs, stage, g_tid);
+    gb.issue(t.cls_slot, t.L, active, g_tid);
+  }
+  NBDT_RSTAMP(2)
+  {
+    if (active)
+      for (int k = g_tid; k < t.sched_len; k += joint_of<TPS>() * TPS) {
+        int s[joint_of<TPS>()], b[joint_of<TPS>()], e[joint_of<TPS>()];
+        float acc[joint_of<TPS>()];
+#pragma unroll
+        for (int m = 0; m < joint_of<TPS>(); ++m) {
+          const int km = k + m * TPS;
+          const bool in = km < t.sched_len;
+          s[m] = in ? o.sched[km] : -1;
+          b[m] = in ? o.sched[t.sched_len + km] : 0;
+          e[m] = in ? o.sched[2 * t.sched_len + km] : 0;
+          if (s[m] < 0) b[m] = e[m] = 0;
+          acc[m] = 0.f;
+        }
+        if (t.staged) chains<ChainAdd, joint_of<TPS>()>(stage, b, e, acc);
+#pragma unroll
+        for (int m = 0; m < joint_of<TPS>(); ++m)
+          if (s[m] >= 0) ss[s[m]] = acc[m] / (float)(e[m] - b[m]);
+      }
+    __syncthreads();
+  }
+  NBDT_RSTAMP(3)
+#pragma nounroll
+  for (int rep = 0; rep < 2; ++rep) {  // second trip: the same code with a warm instruction cache (tsv[7])
+    node_softmax<TPS>(t, o, active, g_tid, ss, ps);
+    if (rep == 0) NBDT_RSTAMP(7) else NBDT_RSTAMP(4)
+  }
+  stage_paths<TPS>(t, ps, stage, g_tid, gb);
+  NBDT_RSTAMP(5)
+  if (active)
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float p[joint_of<TPS>()];
+      class_chains<TPS, ChainMul>(t, o, c0, ps, stage, 1.0f, p);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (c0 + m * TPS < t.C) P[sample * t.C + c0 + m * TPS] = p[m];
+    }
+  __syncthreads();
+  NBDT_RSTAMP(6)
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) P[(threadIdx.x >> 6) * 8 + i] = (float)(tsv[i] - tsv[0]);
+#else
+  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, stage, ga, gb, t.cls_slot);
+  node_softmax<TPS>(t, o, active, g_tid, ss, ps);
+  stage_paths<TPS>(t, ps, stage, g_tid, gb);
+  if (active)
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float p[joint_of<TPS>()];
+      class_chains<TPS, ChainMul>(t, o, c0, ps, stage, 1.0f, p);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (c0 + m * TPS < t.C) P[sample * t.C + c0 + m * TPS] = p[m];
+    }
+#endif
 }
 
 // shared tail of the two backward flavours: Pg (= P*g per class) is in `pq`; ss is overwritten by
-// G then ds; result accumulated on top of `base` per class.
+// G, then by dL/ds already divided by the slot's leaf count (the term every leaf of the slot receives), and
+// those terms are staged along the class paths for class_chains<ChainAdd>.
 template <int TPS>
-__device__ __forceinline__ void tree_backward(const TreeView& t, bool active, int g_tid, float* ss,
-                                              const float* ps, const float* pq) {
-  if (active)
-    for (int s = g_tid; s < t.R; s += TPS) {
-      const int b = t.slot_off[s], e = t.slot_off[s + 1];
-      float acc = 0.f;
-      for (int j = b; j < e; ++j) acc = acc + pq[t.slot_cls[j]];
-      ss[s] = acc;  // G[slot]
-    }
-  __syncthreads();
+__device__ __forceinline__ void tree_backward(const TreeView& t, const TreeLds& o, bool active, int g_tid, float* ss,
+                                              const float* ps, const float* pq, float* stage, Gather<TPS>& ga,
+                                              Gather<TPS>& gb) {
+  slot_sums<TPS, false>(t, o, pq, stage, ss, active, g_tid, ga, gb, t.cls_slot);  // G[slot]
   if (active)
     for (int n = g_tid; n < t.N; n += TPS) {
-      const int b = t.node_off[n], e = t.node_off[n + 1];
+      const int b = o.node_off[n], e = o.node_off[n + 1];
       float tot = 0.f;
       for (int s = b; s < e; ++s) tot = tot + ss[s];
-      for (int s = b; s < e; ++s) ss[s] = ss[s] - ps[s] * tot;  // dL/ds
+      for (int s = b; s < e; ++s) {
+        const float ds = ss[s] - ps[s] * tot;  // dL/ds
+        ss[s] = ds / (float)(o.slot_off[s + 1] - o.slot_off[s]);
+      }
     }
   __syncthreads();
+  stage_paths<TPS>(t, ss, stage, g_tid, gb);
 }
 
-__device__ __forceinline__ float class_grad(const TreeView& t, int c, const float* ds) {
+// VJP of the mean over a slot's leaves, from per-slot gradients in global memory (nbdt_node_logits_backward)
+__device__ __forceinline__ float class_grad_direct(const TreeView& t, int c, const float* ds) {
   float acc = 0.f;
   const int b = t.cls_off[c], e = t.cls_off[c + 1];
   for (int j = b; j < e; ++j) {
@@ -199,60 +549,91 @@ __device__ __forceinline__ float class_grad(const TreeView& t, int c, const floa
 }
 
 template <int TPS, typename LD>
-__global__ __launch_bounds__(kBlock) void soft_bwd_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+__global__ __launch_bounds__(block_of(TPS)) void soft_bwd_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
                                                           const float* __restrict__ gP,
                                                           float* __restrict__ gz) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = kBlock / TPS;
+  constexpr int SPB = block_of(TPS) / TPS;
   const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
   const int64_t sample = (int64_t)blockIdx.x * SPB + g;
   const bool active = sample < B;
-  const int stride = 2 * t.C + 2 * t.R;
-  float* zs = lds + (size_t)g * stride;
+  const int stride = 2 * t.C + 2 * t.R + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
   float* ss = zs + t.C;
   float* ps = ss + t.R;
   float* pq = ps + t.R;
-  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
-  node_softmax<TPS>(t, active, g_tid, ss, ps);
+  float* stage = pq + t.C;
+  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, stage, ga, gb, t.cls_slot);
+  node_softmax<TPS>(t, o, active, g_tid, ss, ps);
+  stage_paths<TPS>(t, ps, stage, g_tid, gb);
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);  // for the G sums of tree_backward
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) pq[c] = path_product(t, c, ps) * gP[sample * t.C + c];
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float p[joint_of<TPS>()];
+      class_chains<TPS, ChainMul>(t, o, c0, ps, stage, 1.0f, p);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (c0 + m * TPS < t.C) pq[c0 + m * TPS] = p[m] * gP[sample * t.C + c0 + m * TPS];
+    }
   __syncthreads();
-  tree_backward<TPS>(t, active, g_tid, ss, ps, pq);
+  tree_backward<TPS>(t, o, active, g_tid, ss, ps, pq, stage, ga, gb);
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) gz[sample * t.C + c] = class_grad(t, c, ss);
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float d[joint_of<TPS>()];
+      class_chains<TPS, ChainAdd>(t, o, c0, ss, stage, 0.f, d);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (c0 + m * TPS < t.C) gz[sample * t.C + c0 + m * TPS] = d[m];
+    }
 }
 
 // SoftTreeSupLoss forward+backward for criterion = nn.CrossEntropyLoss() (mean reduction):
 //   row = w_x*(lse(z) - z[y]) + w_t*(lse(P) - P[y])     (P fed to CE as if logits, loss.py:266)
 //   gz  = scale*( w_x*(softmax(z) - 1[y]) + J^T * w_t*(softmax(P) - 1[y]) )
 template <int TPS, typename LD>
-__global__ __launch_bounds__(kBlock) void soft_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+__global__ __launch_bounds__(block_of(TPS)) void soft_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
                                                            const int64_t* __restrict__ y, float w_x,
                                                            float w_t, float scale,
                                                            float* __restrict__ row_loss,
                                                            float* __restrict__ gz) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = kBlock / TPS;
+  constexpr int SPB = block_of(TPS) / TPS;
   const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
   const int64_t sample = (int64_t)blockIdx.x * SPB + g;
   const bool active = sample < B;
-  const int stride = 3 * t.C + 2 * t.R + 8;
-  float* zs = lds + (size_t)g * stride;
+  const int stride = 3 * t.C + 2 * t.R + 16 + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
   float* ss = zs + t.C;
   float* ps = ss + t.R;
   float* pq = ps + t.R;
   float* gx = pq + t.C;
   float* red = gx + t.C;
-  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
-  node_softmax<TPS>(t, active, g_tid, ss, ps);
+  float* stage = red + 16;
+  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, stage, ga, gb, t.cls_slot);
+  node_softmax<TPS>(t, o, active, g_tid, ss, ps);
+  stage_paths<TPS>(t, ps, stage, g_tid, gb);
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);  // for the G sums of tree_backward
 
   float mz = -INFINITY, mp = -INFINITY;
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) {
-      const float p = path_product(t, c, ps);
-      pq[c] = p;
-      mp = fmaxf(mp, p);
-      mz = fmaxf(mz, zs[c]);
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float p[joint_of<TPS>()];
+      class_chains<TPS, ChainMul>(t, o, c0, ps, stage, 1.0f, p);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m) {
+        const int c = c0 + m * TPS;
+        if (c < t.C) {
+          pq[c] = p[m];
+          mp = fmaxf(mp, p[m]);
+          mz = fmaxf(mz, zs[c]);
+        }
+      }
     }
   mz = group_max<TPS>(mz, red, g_tid);
   mp = group_max<TPS>(mp, red, g_tid);
@@ -279,9 +660,15 @@ __global__ __launch_bounds__(kBlock) void soft_loss_kernel(TreeView t, const voi
     if (!valid && g_tid == 0) row_loss[sample] = __uint_as_float(0x7fc00000u);  // loud: NaN loss
   }
   __syncthreads();
-  tree_backward<TPS>(t, active, g_tid, ss, ps, pq);
+  tree_backward<TPS>(t, o, active, g_tid, ss, ps, pq, stage, ga, gb);
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) gz[sample * t.C + c] = gx[c] + class_grad(t, c, ss);
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float d[joint_of<TPS>()];
+      class_chains<TPS, ChainAdd>(t, o, c0, ss, stage, 0.f, d);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (c0 + m * TPS < t.C) gz[sample * t.C + c0 + m * TPS] = gx[c0 + m * TPS] + d[m];
+    }
 }
 
 // HardTreeSupLoss forward+backward for criterion = nn.CrossEntropyLoss() (nbdt/loss.py:212-257):
@@ -292,23 +679,27 @@ __global__ __launch_bounds__(kBlock) void soft_loss_kernel(TreeView t, const voi
 // The nodes on the label's path are exactly the class->slot CSR row of y; a class listed under two
 // children of one node counts once, for the first child (model.py:135 `cls[0]`).
 template <int TPS, typename LD>
-__global__ __launch_bounds__(kBlock) void hard_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+__global__ __launch_bounds__(block_of(TPS)) void hard_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
                                                            const int64_t* __restrict__ y, float w_x,
                                                            float w_h, float scale,
                                                            float* __restrict__ row_loss,
                                                            float* __restrict__ gz) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = kBlock / TPS;
+  constexpr int SPB = block_of(TPS) / TPS;
   const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
   const int64_t sample = (int64_t)blockIdx.x * SPB + g;
   const bool active = sample < B;
-  const int stride = 2 * t.C + 2 * t.R + 8;
-  float* zs = lds + (size_t)g * stride;
+  const int stride = 2 * t.C + 2 * t.R + 16 + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
   float* ss = zs + t.C;
   float* ds = ss + t.R;
   float* gx = ds + t.R;
   float* red = gx + t.C;
-  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
+  float* stage = red + 16;
+  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, stage, ga, gb, t.cls_slot);
   if (active)
     for (int s = g_tid; s < t.R; s += TPS) ds[s] = 0.f;
   __syncthreads();
@@ -321,24 +712,25 @@ __global__ __launch_bounds__(kBlock) void hard_loss_kernel(TreeView t, const voi
   }
   float tree_rows = 0.f;
   if (valid) {
-    const int pb = t.cls_off[yy], pe = t.cls_off[yy + 1];
+    const int pb = o.cls_off[yy], pe = o.cls_off[yy + 1];
     for (int j = pb + g_tid; j < pe; j += TPS) {
       const int s = t.cls_slot[j];
       // node owning slot s: last n with node_off[n] <= s
       int lo = 0, hi = t.N - 1;
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (t.node_off[mid] <= s) lo = mid; else hi = mid - 1;
+        if (o.node_off[mid] <= s) lo = mid; else hi = mid - 1;
       }
-      const int b = t.node_off[lo], e = t.node_off[lo + 1];
+      const int b = o.node_off[lo], e = o.node_off[lo + 1];
       if (j > pb && t.cls_slot[j - 1] >= b) continue;  // same node, later child: not the first
       float m = ss[b];
       for (int q = b + 1; q < e; ++q) m = fmaxf(m, ss[q]);
       float sum = 0.f;
       for (int q = b; q < e; ++q) sum = sum + expf(ss[q] - m);
       tree_rows += (logf(sum) + m) - ss[s];
-      for (int q = b; q < e; ++q)
-        ds[q] = (expf(ss[q] - m) / sum - (q == s ? 1.f : 0.f)) * (w_h * scale);
+      for (int q = b; q < e; ++q)  // the term each leaf of slot q receives: dL/ds over the slot's leaf count
+        ds[q] = (expf(ss[q] - m) / sum - (q == s ? 1.f : 0.f)) * (w_h * scale) /
+                (float)(o.slot_off[q + 1] - o.slot_off[q]);
     }
   }
   tree_rows = group_sum<TPS>(tree_rows, red, g_tid);
@@ -360,8 +752,15 @@ __global__ __launch_bounds__(kBlock) void hard_loss_kernel(TreeView t, const voi
     if (!valid && g_tid == 0) row_loss[sample] = __uint_as_float(0x7fc00000u);  // loud: NaN loss
   }
   __syncthreads();
+  stage_paths<TPS>(t, ds, stage, g_tid, gb);
   if (active)
-    for (int c = g_tid; c < t.C; c += TPS) gz[sample * t.C + c] = gx[c] + class_grad(t, c, ds);
+    for (int c0 = g_tid; c0 < t.C; c0 += joint_of<TPS>() * TPS) {
+      float d[joint_of<TPS>()];
+      class_chains<TPS, ChainAdd>(t, o, c0, ds, stage, 0.f, d);
+#pragma unroll
+      for (int m = 0; m < joint_of<TPS>(); ++m)
+        if (c0 + m * TPS < t.C) gz[sample * t.C + c0 + m * TPS] = gx[c0 + m * TPS] + d[m];
+    }
 }
 
 // VJP of the node-logit map (nbdt/model.py:94-99): gz[b,c] = sum over slots s holding c of
@@ -372,7 +771,7 @@ __global__ __launch_bounds__(kBlock) void node_logits_bwd_kernel(TreeView t, con
   if (i >= B * t.C) return;
   const int64_t b = i / t.C;
   const int c = (int)(i - b * t.C);
-  gz[i] = class_grad(t, c, gs + b * t.R);
+  gz[i] = class_grad_direct(t, c, gs + b * t.R);
 }
 
 __global__ __launch_bounds__(kBlock) void mean_kernel(const float* __restrict__ rows, int64_t n,
@@ -388,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void mean_kernel(const float* __restrict__ 
 }
 
 template <int TPS, typename LD>
-__global__ __launch_bounds__(kBlock) void hard_fwd_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+__global__ __launch_bounds__(block_of(TPS)) void hard_fwd_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
                                                           int64_t* __restrict__ pred,
                                                           float* __restrict__ onehot,
                                                           int32_t* __restrict__ path_node,
@@ -396,25 +795,40 @@ __global__ __launch_bounds__(kBlock) void hard_fwd_kernel(TreeView t, const void
                                                           float* __restrict__ path_prob,
                                                           float* __restrict__ path_entropy) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = kBlock / TPS;
+  constexpr int SPB = block_of(TPS) / TPS;
   const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
   const int64_t sample = (int64_t)blockIdx.x * SPB + g;
   const bool active = sample < B;
-  const int stride = t.C + t.R + 8;
-  float* zs = lds + (size_t)g * stride;
+  const int stride = t.C + t.R + 8 + 2 * t.N + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<true>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
   float* ss = zs + t.C;
   int* res = (int*)(ss + t.R);
-  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
+  int* best_of = res + 8;        // [N] winning slot of every inner node
+  int* next_of = best_of + t.N;  // [N] where that slot leads (inner node, or -(class+1))
+  float* stage = (float*)(next_of + t.N);
+  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, stage, ga, gb, nullptr);
+  // every node decides in parallel; the walk below is then one LDS hop per level
+  if (active)
+    for (int n = g_tid; n < t.N; n += TPS) {
+      const int b = o.node_off[n], e = o.node_off[n + 1];
+      int best = b;
+      for (int s = b + 1; s < e; ++s)
+        if (ss[s] > ss[best]) best = s;  // first maximum wins (torch.max, model.py:113)
+      best_of[n] = best;
+      next_of[n] = o.slot_next[best];
+    }
+  __syncthreads();
   if (active && g_tid == 0) {
     int n = t.root, cls = -1;
     const bool want = path_node != nullptr;
     int d = 0;
     for (; d < t.max_depth; ++d) {
-      const int b = t.node_off[n], e = t.node_off[n + 1];
-      int best = b;
-      for (int s = b + 1; s < e; ++s)
-        if (ss[s] > ss[best]) best = s;  // first maximum wins (torch.max, model.py:113)
+      const int best = best_of[n];
       if (want) {
+        const int b = o.node_off[n], e = o.node_off[n + 1];
         const float m = ss[best];
         float sum = 0.f;
         for (int s = b; s < e; ++s) sum = sum + expf(ss[s] - m);
@@ -433,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void hard_fwd_kernel(TreeView t, const void
         path_prob[o] = expf(ss[best] - m) / sum;
         path_entropy[o] = -h;
       }
-      const int nx = t.slot_next[best];
+      const int nx = next_of[n];
       if (nx >= 0) {
         n = nx;
       } else {
@@ -458,29 +872,32 @@ __global__ __launch_bounds__(kBlock) void hard_fwd_kernel(TreeView t, const void
 }
 
 template <int TPS, typename LD>
-__global__ __launch_bounds__(kBlock) void node_outputs_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+__global__ __launch_bounds__(block_of(TPS)) void node_outputs_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
                                                               float* __restrict__ logits,
                                                               float* __restrict__ probs,
                                                               int64_t* __restrict__ preds,
                                                               float* __restrict__ entropy) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = kBlock / TPS;
+  constexpr int SPB = block_of(TPS) / TPS;
   const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
   const int64_t sample = (int64_t)blockIdx.x * SPB + g;
   const bool active = sample < B;
-  const int stride = t.C + 2 * t.R;
-  float* zs = lds + (size_t)g * stride;
+  const int stride = t.C + 2 * t.R + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
   float* ss = zs + t.C;
   float* ps = ss + t.R;
-  load_and_node_logits<TPS, LD>(t, z, sample * ldz, active, g_tid, zs, ss);
-  node_softmax<TPS>(t, active, g_tid, ss, ps);
+  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, ps + t.R, ga, gb, nullptr);
+  node_softmax<TPS>(t, o, active, g_tid, ss, ps);
   if (!active) return;
   for (int s = g_tid; s < t.R; s += TPS) {
     if (logits) logits[sample * t.R + s] = ss[s];
     if (probs) probs[sample * t.R + s] = ps[s];
   }
   for (int n = g_tid; n < t.N; n += TPS) {
-    const int b = t.node_off[n], e = t.node_off[n + 1];
+    const int b = o.node_off[n], e = o.node_off[n + 1];
     if (preds) {
       int best = b;
       for (int s = b + 1; s < e; ++s)
@@ -500,6 +917,49 @@ extern "C" int nbdt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// lanes per sample: one wave for the smallest hierarchies, 4 waves up to 512 child slots, 16 beyond.  At one
+// sample per block every phase is a chain of LDS round trips and dependent ALU work that only more waves of
+// the same sample can overlap.
+static int pick_tps(int C, int R) { return (C <= 64 && R <= 64) ? 64 : (C <= 512 && R <= 512) ? 256 : 1024; }
+
+// Order in which the lanes of a sample's group take the slots.  One lane folds one slot (the fp32 order is the
+// contract), so a wave is busy for the longest slot of each 64 it holds: slots are sorted by length, cut into
+// chunks of 64, and the chunks dealt to the group's waves longest-processing-time first, so the wave that gets
+// the 500-leaf root children gets little else.  Row k of the result is what the group does in its k-th pass:
+// [rows][lanes] slot ids, -1 where a wave has run out; then the same shape of first / one-past-last elements.
+static void build_slot_schedule(int R, const int32_t* slot_off, int lanes, std::vector<int32_t>* out, int* len) {
+  std::vector<int> order(R);
+  for (int s = 0; s < R; ++s) order[s] = s;
+  auto length = [&](int s) { return slot_off[s + 1] - slot_off[s]; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return length(a) > length(b); });
+  const int waves = lanes / 64, chunks = (R + 63) / 64;
+  std::vector<std::vector<int>> mine(waves);
+  std::vector<long> load(waves, 0);
+  for (int c = 0; c < chunks; ++c) {  // chunks come longest first
+    const int longest = length(order[c * 64]);
+    int w = 0;
+    for (int i = 1; i < waves; ++i)
+      if (load[i] < load[w]) w = i;
+    mine[w].push_back(c);
+    load[w] += 64 + 8L * longest;  // a pass costs a fixed part plus the longest chain in it
+  }
+  size_t rows = 0;
+  for (auto& m : mine) rows = std::max(rows, m.size());
+  const int n = (int)rows * lanes;
+  out->assign((size_t)3 * n, -1);
+  for (int w = 0; w < waves; ++w)
+    for (size_t k = 0; k < mine[w].size(); ++k)
+      for (int l = 0; l < 64; ++l) {
+        const int i = mine[w][k] * 64 + l;
+        if (i >= R) break;
+        const int at = (int)k * lanes + w * 64 + l, s = order[i];
+        (*out)[at] = s;
+        (*out)[n + at] = slot_off[s];
+        (*out)[2 * n + at] = slot_off[s + 1];
+      }
+  *len = n;
 }
 
 extern "C" int nbdt_tree_create(int device, int C, int N, int root, const int32_t* node_off,
@@ -545,9 +1005,13 @@ extern "C" int nbdt_tree_create(int device, int C, int N, int root, const int32_
   int prev = 0;
   NBDT_HIP_CHECK(hipGetDevice(&prev));
   NBDT_HIP_CHECK(hipSetDevice(device));
+  std::vector<int32_t> sched;
+  int sched_len = 0;
+  build_slot_schedule(R, slot_off, pick_tps(C, R), &sched, &sched_len);
   nbdt_tree* t = new nbdt_tree();
   t->device = device; t->C = C; t->N = N; t->R = R; t->L = L; t->root = root; t->max_depth = max_depth;
-  const size_t n_ints = (size_t)(N + 1) + (R + 1) + L + (C + 1) + L + R;
+  t->sched_len = sched_len;
+  const size_t n_ints = (size_t)(N + 1) + (R + 1) + L + (C + 1) + L + R + sched.size();
   hipError_t e = hipMalloc((void**)&t->d_all, n_ints * sizeof(int32_t));
   if (e != hipSuccess) {
     delete t;
@@ -567,6 +1031,7 @@ extern "C" int nbdt_tree_create(int device, int C, int N, int root, const int32_
   put(cls_off, C + 1, &t->cls_off);
   put(cls_slot, L, &t->cls_slot);
   put(slot_next, R, &t->slot_next);
+  put(sched.data(), sched.size(), &t->sched);
   e = hipMemcpy(t->d_all, host, n_ints * sizeof(int32_t), hipMemcpyHostToDevice);
   delete[] host;
   (void)hipSetDevice(prev);
@@ -588,27 +1053,53 @@ extern "C" int nbdt_tree_destroy(nbdt_tree* t) {
 
 extern "C" int nbdt_tree_max_depth(const nbdt_tree* t) { return t ? t->max_depth : 0; }
 
-// threads per sample: one wave for small hierarchies, the whole block for large ones
-static int pick_tps(const nbdt_tree* t) { return (t->C > 256 || t->R > 512) ? 256 : 64; }
+static int pick_tps(const nbdt_tree* t) { return pick_tps(t->C, t->R); }
 
-#define NBDT_DISPATCH_RULES(KERNEL, FLOATS_PER_SAMPLE, ...)                                          \
+// One launch.  The per-sample LDS row is `base_floats` plus, when it fits, an L-float staging area for the
+// ordered chains (TreeView::staged); hierarchies too deep for that (L grows with the sum of leaf depths) take
+// the direct-indexed chains, slower but the same arithmetic.
+constexpr size_t kLdsBytes = 160 * 1024;
+constexpr size_t kStagePad = 4;  // floats of slack behind the last staging row (chain() reads whole blocks)
+
+template <typename... KA, typename... A>
+static int launch_rules(void (*kernel)(KA...), unsigned grid, int block, size_t shmem, hipStream_t st,
+                        A... args) {
+  if (shmem > 64 * 1024)
+    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, st, args...);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+#define NBDT_DISPATCH_RULES(KERNEL, NEXT, BASE_FLOATS, ...)                                                \
   do {                                                                                               \
     const int tps = pick_tps(t);                                                                     \
-    const int spb = kBlock / tps;                                                                    \
-    const size_t shmem = (size_t)spb * (FLOATS_PER_SAMPLE) * sizeof(float);                          \
-    NBDT_REQUIRE(shmem <= 64 * 1024, "hierarchy too large for LDS");                                \
+    const int spb = block_of(tps) / tps;                                                             \
+    size_t floats = (size_t)(BASE_FLOATS);                                                           \
+    v.tl_ints = tree_lds_ints(t, NEXT);                                                              \
+    v.staged = ((size_t)v.tl_ints + (size_t)spb * (floats + t->L) + kStagePad) * sizeof(float) <= kLdsBytes; \
+    if (v.staged) floats += t->L;                                                                    \
+    const size_t shmem = ((size_t)v.tl_ints + (size_t)spb * floats + kStagePad) * sizeof(float);     \
+    NBDT_REQUIRE(shmem <= kLdsBytes, "hierarchy too large for LDS");                                 \
     const unsigned grid = (unsigned)((B + spb - 1) / spb);                                           \
     hipStream_t st = (hipStream_t)stream;                                                            \
+    int lrc;                                                                                         \
+    const int blk = block_of(tps);                                                                   \
     if (tps == 64) {                                                                                 \
-      if (ztype == NBDT_F32) hipLaunchKernelGGL((KERNEL<64, LoadF32>), dim3(grid), dim3(kBlock), shmem, st, __VA_ARGS__);   \
-      else if (ztype == NBDT_BF16) hipLaunchKernelGGL((KERNEL<64, LoadBF16>), dim3(grid), dim3(kBlock), shmem, st, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<64, LoadF16>), dim3(grid), dim3(kBlock), shmem, st, __VA_ARGS__);                     \
+      if (ztype == NBDT_F32) lrc = launch_rules(KERNEL<64, LoadF32>, grid, blk, shmem, st, __VA_ARGS__);   \
+      else if (ztype == NBDT_BF16) lrc = launch_rules(KERNEL<64, LoadBF16>, grid, blk, shmem, st, __VA_ARGS__); \
+      else lrc = launch_rules(KERNEL<64, LoadF16>, grid, blk, shmem, st, __VA_ARGS__);               \
+    } else if (tps == 256) {                                                                         \
+      if (ztype == NBDT_F32) lrc = launch_rules(KERNEL<256, LoadF32>, grid, blk, shmem, st, __VA_ARGS__);  \
+      else if (ztype == NBDT_BF16) lrc = launch_rules(KERNEL<256, LoadBF16>, grid, blk, shmem, st, __VA_ARGS__); \
+      else lrc = launch_rules(KERNEL<256, LoadF16>, grid, blk, shmem, st, __VA_ARGS__);              \
     } else {                                                                                         \
-      if (ztype == NBDT_F32) hipLaunchKernelGGL((KERNEL<256, LoadF32>), dim3(grid), dim3(kBlock), shmem, st, __VA_ARGS__);  \
-      else if (ztype == NBDT_BF16) hipLaunchKernelGGL((KERNEL<256, LoadBF16>), dim3(grid), dim3(kBlock), shmem, st, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<256, LoadF16>), dim3(grid), dim3(kBlock), shmem, st, __VA_ARGS__);                    \
+      if (ztype == NBDT_F32) lrc = launch_rules(KERNEL<1024, LoadF32>, grid, blk, shmem, st, __VA_ARGS__); \
+      else if (ztype == NBDT_BF16) lrc = launch_rules(KERNEL<1024, LoadBF16>, grid, blk, shmem, st, __VA_ARGS__); \
+      else lrc = launch_rules(KERNEL<1024, LoadF16>, grid, blk, shmem, st, __VA_ARGS__);             \
     }                                                                                                \
-    NBDT_LAUNCH_CHECK();                                                                             \
+    if (lrc) return lrc;                                                                             \
   } while (0)
 
 static int check_common(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz) {
@@ -626,7 +1117,7 @@ extern "C" int nbdt_soft_forward(const nbdt_tree* t, const void* z, int ztype, i
   if (B == 0) return NBDT_OK;
   NBDT_REQUIRE(P != nullptr, "null output");
   TreeView v = view_of(t);
-  NBDT_DISPATCH_RULES(soft_fwd_kernel, t->C + 2 * t->R, v, z, B, ldz, P);
+  NBDT_DISPATCH_RULES(soft_fwd_kernel, false, t->C + 2 * t->R, v, z, B, ldz, P);
   return NBDT_OK;
 }
 
@@ -637,7 +1128,7 @@ extern "C" int nbdt_soft_backward(const nbdt_tree* t, const void* z, int ztype, 
   if (B == 0) return NBDT_OK;
   NBDT_REQUIRE(gP != nullptr && gz != nullptr, "null gradient buffer");
   TreeView v = view_of(t);
-  NBDT_DISPATCH_RULES(soft_bwd_kernel, 2 * t->C + 2 * t->R, v, z, B, ldz, gP, gz);
+  NBDT_DISPATCH_RULES(soft_bwd_kernel, false, 2 * t->C + 2 * t->R, v, z, B, ldz, gP, gz);
   return NBDT_OK;
 }
 
@@ -650,7 +1141,7 @@ extern "C" int nbdt_soft_tree_loss(const nbdt_tree* t, const void* z, int ztype,
   NBDT_REQUIRE(B > 0, "empty batch has no mean loss");
   TreeView v = view_of(t);
   const float scale = grad_scale / (float)B;
-  NBDT_DISPATCH_RULES(soft_loss_kernel, 3 * t->C + 2 * t->R + 8, v, z, B, ldz, y, w_xent, w_tree, scale,
+  NBDT_DISPATCH_RULES(soft_loss_kernel, false, 3 * t->C + 2 * t->R + 16, v, z, B, ldz, y, w_xent, w_tree, scale,
                       row_loss, gz);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, row_loss, B, loss);
   NBDT_LAUNCH_CHECK();
@@ -666,7 +1157,7 @@ extern "C" int nbdt_hard_tree_loss(const nbdt_tree* t, const void* z, int ztype,
   NBDT_REQUIRE(B > 0, "empty batch has no mean loss");
   TreeView v = view_of(t);
   const float scale = grad_scale / (float)B;
-  NBDT_DISPATCH_RULES(hard_loss_kernel, 2 * t->C + 2 * t->R + 8, v, z, B, ldz, y, w_xent, w_node, scale,
+  NBDT_DISPATCH_RULES(hard_loss_kernel, false, 2 * t->C + 2 * t->R + 16, v, z, B, ldz, y, w_xent, w_node, scale,
                       row_loss, gz);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, row_loss, B, loss);
   NBDT_LAUNCH_CHECK();
@@ -699,7 +1190,7 @@ extern "C" int nbdt_hard_forward(const nbdt_tree* t, const void* z, int ztype, i
                "decision buffers must be all set or all NULL");
   if (B == 0) return NBDT_OK;
   TreeView v = view_of(t);
-  NBDT_DISPATCH_RULES(hard_fwd_kernel, t->C + t->R + 8, v, z, B, ldz, pred, onehot, path_node, path_child,
+  NBDT_DISPATCH_RULES(hard_fwd_kernel, true, t->C + t->R + 8 + 2 * t->N, v, z, B, ldz, pred, onehot, path_node, path_child,
                       path_prob, path_entropy);
   return NBDT_OK;
 }
@@ -710,6 +1201,6 @@ extern "C" int nbdt_node_outputs(const nbdt_tree* t, const void* z, int ztype, i
   if (rc) return rc;
   if (B == 0) return NBDT_OK;
   TreeView v = view_of(t);
-  NBDT_DISPATCH_RULES(node_outputs_kernel, t->C + 2 * t->R, v, z, B, ldz, logits, probs, preds, entropy);
+  NBDT_DISPATCH_RULES(node_outputs_kernel, false, t->C + 2 * t->R, v, z, B, ldz, logits, probs, preds, entropy);
   return NBDT_OK;
 }

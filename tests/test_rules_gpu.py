@@ -124,6 +124,56 @@ def test_full_size_vs_oracle(B, ds, h, pkg_dir):
     assert np.abs(hgz.cpu().numpy().sum(1)).max() < 1e-6
 
 
+def _caterpillar(tmp_path, C):
+    """Every inner node keeps one leaf and hands the rest down: depth C-1, sum of leaf depths ~ C*C/2."""
+    import json
+    leaves = [f"f{i:08d}" for i in range(C)]
+    inner = [f"n{i:08d}" for i in range(C - 1)]
+    links = []
+    for i in range(C - 1):
+        links.append({"source": inner[i], "target": leaves[i]})
+        links.append({"source": inner[i], "target": inner[i + 1] if i + 1 < C - 1 else leaves[C - 1]})
+    pg, pw = str(tmp_path / f"cat{C}.json"), str(tmp_path / f"cat{C}.txt")
+    with open(pg, "w") as f:
+        json.dump({"directed": True, "multigraph": False, "graph": {},
+                   "nodes": [{"id": w} for w in inner + leaves], "links": links}, f)
+    with open(pw, "w") as f:
+        f.write("\n".join(leaves) + "\n")
+    return pg, pw, leaves
+
+
+@pytest.mark.parametrize("C", [640, 900])
+def test_deep_hierarchy_without_lds_stage(C, tmp_path):
+    """A hierarchy whose leaf-depth sum does not fit the LDS staging row (csrc/rules.hip: TreeView::staged = 0)
+    takes the direct-indexed chains: same arithmetic contract."""
+    pg, pw, leaves = _caterpillar(tmp_path, C)
+    tree = Tree(None, path_graph=pg, path_wnids=pw, classes=leaves)
+    otree = O.OracleTree(pg, pw)
+    assert int(tree.flat.slot_off[-1]) * 4 > 160 * 1024
+    gen = torch.Generator().manual_seed(C)
+    B = 6
+    z = torch.randn(B, C, generator=gen) * 3
+    y = torch.randint(0, C, (B,), generator=gen)
+    zd, yd = z.to(DEV), y.to(DEV)
+    handle = tree.device_handle(0)
+    outs = O.node_outputs(otree, z.numpy())
+    logits, probs, preds, ent = (t.cpu().numpy() for t in _C.node_outputs(handle, zd))
+    assert np.array_equal(logits, np.concatenate([o["logits"] for o in outs], 1))
+    assert np.array_equal(preds, np.stack([o["preds"] for o in outs], 1))
+    P = _C.soft_forward(handle, zd).cpu().numpy()
+    np.testing.assert_allclose(P, O.soft_forward(otree, z.numpy(), outs), rtol=2e-4, atol=1e-6)  # 639 factors
+    pred = _C.hard_forward(handle, zd, want_onehot=False)[0].cpu().numpy()
+    assert np.array_equal(pred, O.hard_forward(otree, z.numpy(), outs))
+    loss, gz = _C.soft_tree_loss(handle, zd, yd, 1.0, 1.0)
+    lo, dzo = O.soft_tree_sup_loss(otree, z.numpy(), y.numpy())
+    assert abs(loss.item() - lo) <= 1e-5 * abs(lo)
+    np.testing.assert_allclose(gz.cpu().numpy(), dzo, atol=1e-6, rtol=0)
+    hl, hgz = _C.hard_tree_loss(handle, zd, yd, 1.0, 2.0 / len(tree.inodes))
+    hlo, hdzo = O.hard_tree_sup_loss(otree, z.numpy(), y.numpy())
+    assert abs(hl.item() - hlo) <= 1e-5 * abs(hlo)
+    np.testing.assert_allclose(hgz.cpu().numpy(), hdzo, atol=1e-6, rtol=1e-5)
+
+
 def test_edge_cases(pkg_dir):
     tree = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
     otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))

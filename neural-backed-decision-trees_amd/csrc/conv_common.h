@@ -26,6 +26,7 @@ struct ConvDmaParams {
   const float *aff_scale, *aff_shift;
   int aff_act;         // 0 none, 1 ReLU, 2 swish
   int M, n_blocks, m_blocks, per_xcd;
+  int overlap;         // conv3x3_pp_kernel: the epilogue's LDS is laid out around the next tile's first slice
 };
 }  // namespace nbdt
 
@@ -70,10 +71,29 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 #else
 #define NBDT_EPI_STAMP(i)
 #endif
-template <int NT, bool HAS_RES, int STATS, int NWV = 4>
+// Where the epilogue keeps its LDS: one transposition region per wave, the pixel row table, the block's statistics.
+struct EpiLds {
+  unsigned char* region;   // this wave's 32 rows x (2*BN + 16) bytes
+  int* row_off;            // this wave's 64 entries
+  float* blk_stats;        // [2][BN], shared by the block
+};
+template <int NT, int NWV>
+__device__ __forceinline__ EpiLds epi_lds_packed(unsigned char* smem, int wave) {   // everything from smem + 0
+  constexpr int REGION = 32 * (2 * 32 * NT + 16);
+  EpiLds l;
+  l.region = smem + wave * REGION;
+  l.row_off = (int*)(smem + NWV * REGION) + wave * 64;
+  l.blk_stats = (float*)(smem + NWV * REGION + NWV * 64 * 4);
+  return l;
+}
+struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_entry` runs once every wave of the block has passed the entry barrier (nobody reads the K ring any
+// more) and before the first LDS write: the persistent kernel issues the next tile's first LDS-DMA there.
+template <int NT, bool HAS_RES, int STATS, int NWV = 4, typename HOOK = EpiNoHook>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
-                                              unsigned char* smem, int m0, int n0, int m_blk, int wave, int lane,
-                                              int tid, unsigned* epi_t = nullptr) {
+                                              const EpiLds& lds, int m0, int n0, int m_blk, int wave, int lane,
+                                              int tid, unsigned* epi_t = nullptr, HOOK after_entry = HOOK()) {
   NBDT_EPI_STAMP(0)
   constexpr int BN = 32 * NT;
   constexpr int NTHR = 64 * NWV;
@@ -96,9 +116,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();          // every wave is done with the K ring
   asm volatile("" ::: "memory");
-  unsigned char* region = smem + wave * REGION;
-  int* row_off = (int*)(smem + NWV * REGION) + wave * 64;    // element offset of each of the wave's 64 pixels
-  float* blk_stats = (float*)(smem + NWV * REGION + NWV * 64 * 4);  // [2][BN]
+  after_entry();
+  unsigned char* region = lds.region;
+  int* row_off = lds.row_off;              // element offset of each of the wave's 64 pixels
+  float* blk_stats = lds.blk_stats;        // [2][BN]
   {
     const int m = m0 + wave * 64 + lane;
     row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
   }
 
   static_assert(conv_epilogue_lds_bytes<NT>() <= NSTAGE * STAGE, "epilogue does not fit in the ring");
-  conv_epilogue<NT, HAS_RES, STATS>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
+  conv_epilogue<NT, HAS_RES, STATS>(acc, p, epi_lds_packed<NT, 4>(smem, wave), m0, n0, m_blk, wave, lane, tid);
 }
 
 namespace nbdt {

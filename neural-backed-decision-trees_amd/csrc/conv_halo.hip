@@ -25,6 +25,8 @@
 // slots) and a window of halo slice A(kc) (2 buffers).
 #include "conv_common.h"
 
+#include <algorithm>
+
 // counted wait: the `n` most recent DMA instructions of this wave may stay in flight (immediate operand)
 __device__ __forceinline__ void wait_vm(int n) {
   switch (n) {
@@ -72,6 +74,7 @@ __device__ __forceinline__ TileOrigin tile_origin(const nbdt_conv_desc& d, const
 #endif
 #ifndef NBDT_PP_TIMING
 #define NBDT_PP_TIMING 0   // 1: s_memtime stamps around the segments of every step, per-wave sums in g_pp_timing
+                           // 2: four stamps per block + HW_ID / XCC_ID (scratch/pp_trace.py: a CU's timeline)
 #endif
 #if NBDT_PP_TIMING
 __device__ unsigned g_pp_epi[8192 * 8];        // [block*8 + wave][8]: epilogue phases
@@ -114,14 +117,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   constexpr int W_INSTR = W_BYTES / 1024;
   constexpr int abl = NBDT_PP_ABLATE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [A buf 0][A buf 1][W ring x3]
+#if NBDT_PP_TIMING == 2
+  unsigned tr_entry = stamp();   // entry of the block, then the end of the previous tile
+#endif
 
+  // Persistent blocks: block b sits on XCD b & 7 (round-robin dispatch) and walks that XCD's contiguous item
+  // range with the XCD's other blocks, items  xcd * per_xcd + (b >> 3) + j * (gridDim / 8).
   const int bid = blockIdx.x;
-  const int item = (bid & 7) * p.per_xcd + (bid >> 3);      // each XCD walks a contiguous item range
-  if (item >= p.m_blocks * p.n_blocks) return;
-  const int m_blk = item / p.n_blocks;
-  const int n_blk = item - m_blk * p.n_blocks;
-  const int m0 = m_blk * BMH;
-  const int n0 = n_blk * BN;
+  const int item_step = gridDim.x >> 3;
+  const int item_end = min(((bid & 7) + 1) * p.per_xcd, p.m_blocks * p.n_blocks);
+  int item = (bid & 7) * p.per_xcd + (bid >> 3);
+  if (item >= item_end) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -141,18 +147,34 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
                                           (unsigned)NBDT_PIN((unsigned)in_u));
   const bf16_t* w_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(w_u >> 32)) << 32) |
                                          (unsigned)NBDT_PIN((unsigned)w_u));
-  const TileOrigin org = tile_origin(d, hg, m_blk);
-  const int base_pix = NBDT_PIN(org.base_pix), last_pix = NBDT_PIN(org.last_pix);
+  struct Tile {
+    int item, m_blk, n_blk, m0, n0, base_pix;
+    const bf16_t* w_tiles;     // this cout tile's DMA-ordered weight tiles, step 0
+  };
+  auto tile_of = [&](int it) {
+    Tile t;
+    t.item = it;
+    t.m_blk = it / p.n_blocks;
+    t.n_blk = it - t.m_blk * p.n_blocks;
+    t.m0 = t.m_blk * BMH;
+    t.n0 = t.n_blk * BN;
+    t.base_pix = NBDT_PIN(tile_origin(d, hg, t.m_blk).base_pix);
+    t.w_tiles = w_base + (size_t)t.n_blk * kchunks * 9 * (BN * 32);
+    return t;
+  };
+  Tile cur = tile_of(item);
+  const int last_pix = NBDT_PIN(d.B * (d.gh + 2) * (d.gw + 2) - 1);
 #undef NBDT_PIN
 
   // ---- DMA source addressing: every LDS-DMA is  global_load_lds  <32-bit lane offset>, <SGPR base>  -- the
   // wave-uniform part of an address (slice, tap, piece, tile) is scalar arithmetic, the lane part one VGPR.
   // A piece `id` = halo pixels [16 id, 16 id + 16) x 64 B; lane -> pixel lane>>2, LDS chunk position lane&3,
   // which holds source chunk (lane&3) ^ swizzle(pixel); 16 | 16*id so the swizzle (pixel>>2)&3 is per lane.
-  const int a_lane_pix = lane >> 2;
-  const int a_lane_el = (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+  // (the per-lane constants below are recomputed at the top of every tile from an opaque copy of `lane`: kept
+  // live across the epilogue they cost the accumulator pass registers it does not have)
+  int a_lane_pix, a_lane_el;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto issue_a_piece = [&](int buf, int kc, int id) {
+  auto issue_a_piece = [&](int base_pix, int buf, int kc, int id) {
     int lp = a_lane_pix;
     asm volatile("" : "+v"(lp));                      // keep this address math inside the step (registers)
     int px = lp + (base_pix + id * 16);
@@ -162,14 +184,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   // W piece `id` = rows [16 id, 16 id + 16) of a weight tile.  The weights are the DMA-ordered tiles of
   // nbdt_weight_tile_batched: tile (n_blk, kc, tap) IS the swizzled LDS image, stored contiguously in step order,
   // so piece id of step t is  w_tiles + (t * W_INSTR + id) KiB  and every lane reads 16 B at 16 * lane.
-  const unsigned w_voff = lane * 16u;
+  unsigned w_voff;
   const unsigned w_ring = lds_base + 2 * a_bytes;
-  const bf16_t* w_tiles = w_base + (size_t)n_blk * kchunks * 9 * (BN * 32);
   // Blocks run in lockstep (same start, same step time): without the rotation every CU of an XCD would ask its L2
   // for the SAME KiB at the same moment.  Block b starts W_ROT pieces further into the tile.
   const int w_rot = (NBDT_PP_SCHED & 4) ? item % W_INSTR : 0;
   constexpr int IPW = (W_INSTR + NWV - 1) / NWV;
-  auto issue_w = [&](int slot, int t) {
+  auto issue_w = [&](const bf16_t* w_tiles, int slot, int t) {
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
       const int slot_id = wave + NWV * k;
@@ -182,26 +203,31 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   };
 
   f32x16 acc[NT][2];
-#pragma unroll
-  for (int tn = 0; tn < NT; ++tn)
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
-
-  const int frag_row = lane & 31;
-  const int frag_half = lane >> 5;
+  int frag_half;
   int hp0[2];                      // halo index of this lane's two output pixels at tap (0,0)
+  unsigned w_rd0, w_rd1;           // LDS offsets of this lane's weight fragment rows (ks = 0, 1) in ring slot 0
+  auto lane_constants = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    a_lane_pix = ln >> 2;
+    a_lane_el = (((ln & 3) ^ ((ln >> 4) & 3)) << 3);
+    w_voff = ln * 16u;
+    const int frag_row = ln & 31;
+    frag_half = ln >> 5;
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int pl = wave * 64 + tm * 32 + frag_row;
-    const int per_img = hg.rb * d.gw;
-    const int img = pl / per_img;
-    const int rem = pl - img * per_img;
-    const int r = rem / d.gw, c = rem - r * d.gw;
-    hp0[tm] = img * himg + r * hw2 + c;
-  }
-  const int w_frag_off = frag_row * 64 + ((frag_half ^ ((frag_row >> 2) & 3)) << 4);   // ks = 0; ks = 1 is ^ 32
+    for (int tm = 0; tm < 2; ++tm) {
+      const int pl = wave * 64 + tm * 32 + frag_row;
+      const int per_img = hg.rb * d.gw;
+      const int img = pl / per_img;
+      const int rem = pl - img * per_img;
+      const int r = rem / d.gw, c = rem - r * d.gw;
+      hp0[tm] = img * himg + r * hw2 + c;
+    }
+    const int w_frag_off = frag_row * 64 + ((frag_half ^ ((frag_row >> 2) & 3)) << 4);   // ks = 0; ks = 1 is ^ 32
+    w_rd0 = 2 * a_bytes + w_frag_off;
+    w_rd1 = 2 * a_bytes + (w_frag_off ^ 32);
+  };
+  lane_constants();
 
   // ---- everything a load segment needs is prepared one segment EARLIER, inside the previous MFMA segment: a wave
   // issues one instruction per ~4 cycles, a load segment that also computed its 4 swizzled LDS addresses and its
@@ -214,8 +240,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     unsigned a_voff[APW];     // halo pieces: per-lane byte offsets
     int a_n;                  // ... and how many of them this wave issues in L(t)
   };
-  const unsigned w_rd0 = 2 * a_bytes + w_frag_off, w_rd1 = 2 * a_bytes + (w_frag_off ^ 32);
-  const int a_pix0 = base_pix + wave * 16;     // halo pixel of lane 0 of this wave's piece at tap 0
+  int a_pix0 = cur.base_pix + wave * 16;       // halo pixel of lane 0 of this wave's piece at tap 0 (per tile)
   auto prepare = [&](int tapn, int kcn) {     // plan of L(t) for t = (kcn, tapn); tapn is a literal after unrolling
     Plan q;
     int h0 = hp0[0], h1 = hp0[1], lp = a_lane_pix;
@@ -245,22 +270,55 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     return q;
   };
 
-  // ---- prologue: A(0) (every piece), W(0), W(1)
-  if (!(abl & 1)) {
+  // ---- a tile's first LDS-DMA: A(0) (every piece) into halo buffer 0, W(0), W(1) into ring slots 0, 1
+  auto issue_first = [&](const Tile& t) {
+    if (abl & 1) return;
 #pragma unroll
     for (int k = 0; k < 7 * APW; ++k)
-      if (wave + NWV * k < a_instr) issue_a_piece(0, 0, wave + NWV * k);
-    issue_w(0, 0);
-    issue_w(1, 1);
+      if (wave + NWV * k < a_instr) issue_a_piece(t.base_pix, 0, 0, wave + NWV * k);
+    issue_w(t.w_tiles, 0, 0);
+    issue_w(t.w_tiles, 1, 1);
+  };
+  // ---- LDS of the epilogue.  Packed from smem + 0 it overlaps halo buffer 0 and the ring, so the next tile
+  // cannot be started before it is done.  With p.overlap (the launch checked that it fits) the per-wave regions
+  // go into halo buffer 1 and behind ring slot 1 instead, and the next tile's first DMA is issued at the top of
+  // the epilogue: its HBM round trip (10 k of 81 k cycles per tile at 32x32x160, profiles/r02_pp_trace.txt) and
+  // the dispatch gap between two blocks (2.4 k) disappear behind the 8.8 k-cycle epilogue.
+  constexpr int EPI_REGION = 32 * (2 * BN + 16);
+  EpiLds epi_lds = epi_lds_packed<NT, NWV>(smem, wave);
+  if (p.overlap) {
+    const int in_a1 = a_bytes / EPI_REGION;                 // regions that fit into halo buffer 1
+    unsigned char* tail = smem + 2 * a_bytes + 2 * W_BYTES;  // ring slot 2 and everything behind it
+    const int n_tail = NWV - (in_a1 < NWV ? in_a1 : NWV);
+    epi_lds.region = wave < in_a1 ? smem + a_bytes + wave * EPI_REGION : tail + (wave - in_a1) * EPI_REGION;
+    epi_lds.row_off = (int*)(tail + n_tail * EPI_REGION) + wave * 64;
+    epi_lds.blk_stats = (float*)(tail + n_tail * EPI_REGION + NWV * 64 * 4);
   }
+
+  issue_first(cur);
+  for (;;) {   // ======================================= one output tile =======================================
+  const int m_blk = cur.m_blk, m0 = cur.m0, n0 = cur.n0;
+  const bf16_t* w_tiles = cur.w_tiles;
+  item = cur.item;
+  lane_constants();
+  a_pix0 = cur.base_pix + wave * 16;
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
   Plan plan = prepare(0, 0);
   int prev_a = 0;                          // halo pieces this wave issued in the previous load segment
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();            // bP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first DMA (and the last tile's stores)
+  __builtin_amdgcn_s_barrier();            // bP: every wave's pieces have landed; the last epilogue's LDS is free
   if (PP && grp == 1) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-#if NBDT_PP_TIMING
+#if NBDT_PP_TIMING == 2
+  const unsigned tr_loop = stamp();
+#define NBDT_STAMP(acc_)
+#elif NBDT_PP_TIMING
   unsigned tm_l = 0, tm_b1 = 0, tm_m = 0, tm_b2 = 0;
   const unsigned tm_begin = stamp();
   unsigned tm_prev = tm_begin;
@@ -301,7 +359,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       if (!(abl & 1)) {
         const int t2 = kc * 9 + tap + 2;                    // W(t+2) -> ring slot (t+2) % 3 = (tap+2) % 3
-        if (t2 < nk) issue_w((tap + 2) % 3, t2);
+        if (t2 < nk) issue_w(w_tiles, (tap + 2) % 3, t2);
         if (!(abl & 2)) {                                   // pieces (tap*APW + j)*NWV + wave of slice kc+1
 #pragma unroll
           for (int j = 0; j < APW; ++j)
@@ -348,7 +406,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
       NBDT_STAMP(tm_b2)
     }
   }
-#if NBDT_PP_TIMING
+#if NBDT_PP_TIMING == 2
+  const unsigned tr_epi = stamp();
+#elif NBDT_PP_TIMING
   if (lane == 0 && item < 1024) {
     unsigned* o = g_pp_timing + (item * 8 + wave) * 8;
     o[0] = tm_l; o[1] = tm_b1; o[2] = tm_m; o[3] = tm_b2; o[4] = tm_prev - tm_begin; o[5] = nk;
@@ -358,15 +418,33 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   if (PP && grp == 0) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-#if NBDT_PP_TIMING
+  // ---- the next tile of this block, and when its first DMA can go out
+  const int next_item = item + item_step;
+  const bool more = next_item < item_end;
+  const Tile nxt = more ? tile_of(next_item) : cur;
+  const bool early = more && p.overlap && !(abl & 32);
+  auto hook = [&]() {
+    if (early) issue_first(nxt);
+  };
+#if NBDT_PP_TIMING == 2
+  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
+  if (tid == 0 && item < 8192) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned* o = g_pp_timing + item * 8;
+    o[0] = hw; o[1] = xcc; o[2] = tr_entry; o[3] = tr_loop; o[4] = tr_epi; o[5] = stamp();
+  }
+  tr_entry = stamp();
+#elif NBDT_PP_TIMING
   unsigned epi_t[8];
-  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid, epi_t);
+  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, epi_t, hook);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores acknowledged
   epi_t[6] = stamp();
   if (lane == 0 && item < 1024)
     for (int i = 0; i < 6; ++i) g_pp_epi[(item * 8 + wave) * 8 + i] = epi_t[i + 1] - epi_t[i];
 #else
-  if (!(abl & 32)) conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
+  if (!(abl & 32)) conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
 #endif
   if (abl & 32) {   // timing experiment: no epilogue, but every accumulator stays live
     float sum = 0.f;
@@ -378,6 +456,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
         for (int r = 0; r < 16; ++r) sum += acc[tn][tm][r];
     if (sum == 12345.f) p.out[0] = 0;
   }
+  if (!more) break;
+  if (!early) {   // the packed epilogue LDS overlaps halo buffer 0 and the ring: every wave must be out of it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_first(nxt);
+  }
+  cur = nxt;
+  }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -541,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
     if (++tap == 9) { tap = 0; ++kc; }
   }
 
-  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, smem, m0, n0, m_blk, wave, lane, tid);
+  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds_packed<NT, NWV>(smem, wave), m0, n0, m_blk, wave, lane, tid);
 }
 
 namespace nbdt {
@@ -562,8 +648,28 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   size_t shmem = 2 * (size_t)hg.a_bytes + (size_t)3 * BN * BK * 2;
   const size_t epi = conv_epilogue_lds_bytes<NT, NWV>();
   if (shmem < epi) shmem = epi;
+  // The ping-pong kernel is persistent: one block per CU walks its XCD's items (the other two kinds keep one
+  // block per item).  If the epilogue's LDS fits around halo buffer 0 and ring slots 0/1 -- regions in halo
+  // buffer 1 and behind slot 1 -- a tile's first DMA is issued during the previous tile's epilogue.
+  p.overlap = 0;
+  int per_round = p.per_xcd;
+  if (KIND == 0) {
+    constexpr size_t REGION = 32 * (2 * BN + 16);
+    const size_t in_a1 = std::min<size_t>(hg.a_bytes / REGION, NWV);
+    const size_t need = 2 * (size_t)hg.a_bytes + 2 * (size_t)BN * BK * 2 + (NWV - in_a1) * REGION + NWV * 64 * 4 +
+                        2 * BN * 4;
+    if (need <= 160 * 1024) {
+      p.overlap = 1;
+      if (shmem < need) shmem = need;
+    }
+    per_round = std::min(p.per_xcd, 32);     // 32 CUs per XCD
+#ifdef NBDT_PP_NO_PERSIST                    // timing experiment: one block per item, packed epilogue LDS
+    per_round = p.per_xcd;
+    p.overlap = 0;
+#endif
+  }
   static size_t attr_bytes = 0;
-  const dim3 grid(p.per_xcd * 8), blk(64 * NWV);
+  const dim3 grid(per_round * 8), blk(64 * NWV);
 #define NBDT_KERNEL(R, S) \
   (KIND == 2 ? reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>) \
              : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV>))

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_backbone_gpu.py tests/test_engine_gpu.py tests/test_models_gpu.py -x -q 2>&1 | tail -3
+V=scratch/variants/libnbdt_$1.so
+for i in 1 2; do
+for L in "" $V; do
+  echo "== lib ${L:-in-tree}"
+  NBDT_HIP_LIB=$L timeout 600 python bench.py --no-cpu-baseline --agreement-n 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['achieved'], d['roofline']['frac'])"
+done
+done
+NBDT_HIP_LIB=scratch/variants/libnbdt_trace.so python scratch/pp_trace.py 2>&1 | grep "==\|per block" | tee gpurun_out/pp_trace_persist.txt
+NBDT_HIP_LIB=scratch/variants/libnbdt_tim.so python scratch/pp_timing.py 2>&1 | grep -v amdgpu | tee gpurun_out/pp_timing_persist.txt

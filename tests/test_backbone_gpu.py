@@ -497,6 +497,76 @@ BENCH_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("B,H,W,C", [
+    (288, 32, 32, 160),    # 576 tiles on 256 persistent blocks: 2 or 3 tiles each, epilogue LDS in the overlap layout
+    (260, 32, 32, 160),    # 520 tiles: the XCD ranges do not divide evenly
+    (640, 16, 16, 320),    # 320 pixel tiles x 2 cout tiles, overlap layout (41 KB halo buffers)
+    (1280, 8, 8, 640),     # 160 x 4 items, 50 KB halo buffers: persistent, first DMA after the epilogue
+])
+def test_pingpong_kernel_several_tiles_per_block(B, H, W, C):
+    """The ping-pong kernel's blocks are persistent: with more than 256 items a block runs several tiles and issues
+    the next tile's first LDS-DMA while the current epilogue runs (csrc/conv_halo.hip, generation 8).  The 4-wave
+    form of the same segments (one tile per block, 256-pixel tiles, packed epilogue LDS) must produce the same
+    bits: plain forward, forward + residual + statistics, data gradient + BatchNorm-backward sums."""
+    _, xp = _rand_act(B, H, W, C, seed=91)
+    _, w_int = _rand_weight(C, C, 3, seed=92)
+    wb = w_int.to(torch.bfloat16).to(DEV)
+    wd = torch.empty(C, 9, C, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w_int.to(DEV), C, 9, C, None, wd)
+    wt, wdt = ops.weight_tiles(wb), ops.weight_tiles(wd)
+    _, rp = _rand_act(B, H, W, C, seed=93)
+    _, gp = _rand_act(B, H, W, C, seed=94)
+    n_part = ((B * H * W + 255) // 256) * 2 * C
+
+    def fwd(mode, residual, stats):
+        d = _force(ops.conv_fwd_desc(B, H, W, C, C, 3, 1), mode)
+        d.w_tiled = wt.data_ptr()
+        out = ops.padded(B, H, W, C, DEV)
+        part = torch.full((n_part,), float("nan"), device=DEV) if stats else None
+        ops.conv_igemm(d, xp, wb, out, residual=residual, bn_scratch=part)
+        return out, part, ops.last_igemm_kernel()
+
+    for residual, stats in ((None, False), (rp, True)):
+        o8, p8, k8 = fwd(2, residual, stats)
+        o4, p4, k4 = fwd(3, residual, stats)
+        assert (k8, k4) == ("conv3x3_pp_kernel", "conv3x3_pp_kernel/4w")
+        assert torch.equal(o8, o4)
+        _check_border_zero(o8)
+        if stats:
+            m8, r8, m4, r4 = (torch.empty(C, device=DEV) for _ in range(4))
+            ops.bn_finalize(o8, p8, m8, r8)
+            ops.bn_finalize(o4, p4, m4, r4)
+            np.testing.assert_allclose(m8.cpu().numpy(), m4.cpu().numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(r8.cpu().numpy(), r4.cpu().numpy(), rtol=1e-5)
+    # one spot check against fp32 arithmetic (a corner and a middle image), so that "same bits" is not "same bug"
+    for b in (0, B // 2, B - 1):
+        xi = ops.interior(xp)[b:b + 1].float().permute(0, 3, 1, 2)
+        w_oihw = w_int.reshape(C, 3, 3, C).permute(0, 3, 1, 2).to(DEV)
+        ref = F.conv2d(xi, w_oihw, padding=1).permute(0, 2, 3, 1) + ops.interior(rp)[b:b + 1].float()
+        _close_bf16(ops.interior(o8)[b:b + 1], ref.cpu(), f"image {b}")
+
+    g = torch.Generator().manual_seed(95)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_stats(xp, torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV), mean, rstd)
+    res = []
+    for mode in (2, 3):
+        (dd,) = ops.conv_dgrad_descs(B, H, W, C, C, 3, 1)
+        _force(dd, mode)
+        dd.w_tiled = wdt.data_ptr()
+        gx = ops.padded(B, H, W, C, DEV)
+        part = torch.full((n_part,), float("nan"), device=DEV)
+        ops.conv_igemm_bnbwd(dd, gp, wd, gx, xp, mean, rstd, gamma, beta, part)
+        dsum, dg, db = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ops.bn_bwd_fused(gx, xp, mean, rstd, gamma, beta, part, dsum, dg, db, ops.padded(B, H, W, C, DEV))
+        res.append((gx, dg, db, ops.last_igemm_kernel()))
+    assert (res[0][3], res[1][3]) == ("conv3x3_pp_kernel", "conv3x3_pp_kernel/4w")
+    assert torch.equal(res[0][0], res[1][0])
+    scale = res[1][2].abs().mean().item() + res[1][1].abs().mean().item()
+    np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
 @pytest.mark.parametrize("B,H,W,C", BENCH_SHAPES)
 def test_bench_shape_conv_forward_dgrad_wgrad(B, H, W, C):
     """What bench.py executes, at its own tile geometry: forward with residual + statistics epilogue, data

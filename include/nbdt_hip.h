@@ -70,7 +70,12 @@ int nbdt_weight_tile_batched(const void* src_bf16, const int64_t* table, int32_t
  *   slot_cls[slot_off[s] .. slot_off[s+1]) (ascending);  class c lies under slots
  *   cls_slot[cls_off[c] .. cls_off[c+1]) (inode order);  slot_next[s] = inode index of the
  *   child if it is an inner node, else -(class_index)-1.   All arrays are HOST pointers and are
- *   copied to `device`. */
+ *   copied to `device`, together with the order in which a sample's lanes take the slots (longest first, dealt to
+ *   the waves by load: csrc/rules.hip build_slot_schedule).
+ * Size limits of the rules kernels (NBDT_EINVAL "hierarchy too large for LDS" beyond them): the per-sample rows
+ *   (2-3 floats per class and per child slot) plus the offset arrays must fit 160 KB of LDS; when the sum of the
+ *   leaf depths L = slot_off[R] also fits, the kernels stage the gathered operands there (ImageNet-1000: L = 11012),
+ *   otherwise they index through the maps directly -- same results, slower. */
 typedef struct nbdt_tree nbdt_tree;
 int nbdt_tree_create(int device, int num_classes, int num_inodes, int root,
                      const int32_t* node_off, const int32_t* slot_off, const int32_t* slot_cls,

@@ -108,8 +108,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   // loads / output stores (20 lanes = one 320-B pixel row), and -- because the chunk is fixed -- the
   // per-channel sum and sum of squares of the bf16 output fall out of the same pass in registers.  They
   // feed the next BatchNorm (bn_finalize only), replacing a full re-read of the tensor (bn_stats_kernel).
-  constexpr int PITCH = 2 * BN + 16;
-  constexpr int REGION = 32 * PITCH;
+  constexpr int PITCH = 2 * BN + 16;   // a wave's region is 32 rows of it (EpiLds::region)
   constexpr int NCH = BN / 8;            // 8-channel chunks per row
   constexpr int RL = 64 / NCH;           // row lanes: lanes [0, RL*NCH) are active in the row walk
   constexpr int ROW_ITERS = (32 + RL - 1) / RL;

@@ -387,12 +387,29 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
             for (int tm = 0; tm < 2; ++tm)
               acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][tn], pf[ks][tm], acc[tn][tm], 0, 0, 0);
       }
+#ifdef NBDT_PP_DUMMY_VALU   // experiment: how much does extra VALU work in the MFMA shadow cost (an in-LDS BatchNorm pass)?
+      {
+        float d0 = __int_as_float(lane), d1 = d0 + 1.f, d2 = d0 + 2.f, d3 = d0 + 3.f;
+#pragma unroll
+        for (int i = 0; i < NBDT_PP_DUMMY_VALU / 4; ++i) {
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d0) : "v"(d1), "v"(d2));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d1) : "v"(d2), "v"(d3));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d2) : "v"(d3), "v"(d0));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(d3) : "v"(d0), "v"(d1));
+        }
+        asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
+      }
+#endif
       // one MFMA, then at most two of the preparation's VALU / SALU instructions in its shadow, 20 times
       if (!(NBDT_PP_SCHED & 2)) {
 #pragma unroll
         for (int i = 0; i < 4 * NT; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+#ifdef NBDT_PP_DUMMY_VALU
+          __builtin_amdgcn_sched_group_barrier(0x002, 2 + NBDT_PP_DUMMY_VALU / 20 + 1, 0);   // VALU
+#else
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+#endif
           __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
         }
       }

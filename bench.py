@@ -9,7 +9,9 @@ batches (BASELINE.json `metric`, configs[1]: batch 512 per MI355X, fused rules/l
 
 A "step" = zero_grad -> backbone forward -> SoftTreeSupLoss forward+backward (one fused kernel) ->
 backbone backward -> [RCCL all-reduce of gradients, overlapped] -> SGD(momentum .9, wd 5e-4) on one
-batch already resident in HBM.  Weak scaling: 512 images per GPU.  Prints ONE JSON line on rank 0.
+batch already resident in HBM.  In backward the HBM-bound BatchNorm passes run on ~50 CUs BESIDE the MFMA-bound weight
+gradients on the other ~200 (engine.set_cu_share; `cu_share` in the JSON line is the one-pair calibration the first
+warm-up step made; --no-cu-share restores the order without it).  Weak scaling: 512 images per GPU.  Prints ONE JSON line on rank 0.
 
 roofline: the dominant kernel is conv_igemm (forward + data-gradient implicit GEMMs; 2/3 of the
 step's flops).  achieved = algorithmic flops of its launches / their HIP-event durations, measured
@@ -154,6 +156,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every launch on one stream (profiling passes: a kernel's duration is then its own)")
+    ap.add_argument("--no-cu-share", action="store_true",
+                    help="default schedule: weight gradients beside the data gradients, BatchNorm-backward passes on "
+                         "all CUs (engine.set_cu_share(None)); A/B of the CU-sharing schedule")
     ap.add_argument("--agreement-n", type=int, default=512, help="images in the prediction-agreement check (0: skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -177,6 +182,9 @@ def main():
                            hierarchy="induced-wrn28_10_cifar10")
     if args.no_overlap:
         eng.set_overlap(False)
+    # BatchNorm-backward passes on ~50 CUs beside the weight gradients on the other ~200 (engine.set_cu_share): the
+    # first backward of the warm-up times one pair both ways and keeps the schedule only if it is faster on this box
+    eng.set_cu_share(None if args.no_cu_share else 47.0)
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
     y = torch.randint(0, args.classes, (args.batch,), generator=g).to(dev)
@@ -245,6 +253,8 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": round(loss_val, 4)},
         "step_mfma_frac": round(value / world * GFLOP_PER_IMG_TRAIN / 1e3 / PEAK_BF16_TFLOPS, 4),
     }
+    if eng.cu_share_report is not None:
+        out["cu_share"] = eng.cu_share_report
     if world > 1:
         out["comm"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                        "allreduce_bytes_per_rank": int(eng.store.grad.numel()) * 4, "buckets": 3,

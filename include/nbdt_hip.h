@@ -188,9 +188,17 @@ typedef struct nbdt_wgrad_desc {
   int32_t g_bs, g_hs, g_ws, g_base;
   int32_t variant;              /* dense 3x3 stride-1 launches: 0 = pick from the problem size; 2 = force the 8-wave
                                    two-pipeline kernel, 3 = force the 4-wave one (tests, A/B measurements) */
+  int32_t cu_budget;            /* dense 3x3 stride-1 launches: 0 = size the pixel split for all 256 CUs; n = for n of
+                                   them (32..256), so that an HBM-bound pass launched on another stream keeps the
+                                   rest: a weight-gradient block takes a CU's whole register file, the two kernels
+                                   never share one (probes/cu_share_probe.hip) */
 } nbdt_wgrad_desc;
 int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw,
                     void* stream);
+/* thread blocks the launch above will use for this descriptor (its cu_budget included) when it takes the 8-wave dense
+ * 3x3 kernel -- one block per CU, so 256 minus this is what a concurrent HBM-bound pass may take
+ * (nbdt_bn_bwd_apply_cus); 0 for every other kernel.  No device work. */
+int nbdt_conv_wgrad_blocks(const nbdt_wgrad_desc* d);
 
 /* fp32 master [cout][taps][cin] -> bf16 copy in the same order, and (optional) the dgrad copy
  * wd[cin][taps][cout] with the tap order reversed (wd[ci][t][co] = w[co][taps-1-t][ci]) */
@@ -241,6 +249,14 @@ int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float*
                       const float* save_rstd, const float* gamma, const float* beta, const float* dsum,
                       const void* gx_add, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
                       void* gx, void* g_resid, void* stream);
+/* nbdt_bn_bwd_apply with relu = 1, y = NULL, g_resid = NULL on `cus` CUs only (one persistent block each): the pass is
+ * HBM-bound and needs few of them (64 CUs stream 3.0 TB/s, 96 4.1 TB/s, all 256 5.6 TB/s), so an MFMA-bound launch on
+ * another stream -- nbdt_conv_wgrad with nbdt_wgrad_desc.cu_budget = 256 - cus -- runs on the rest at the same
+ * time.  (Blocks of the ordinary launch land on every CU and keep a weight-gradient block, which takes a CU's whole
+ * register file, from starting.)  Same arithmetic, same results as nbdt_bn_bwd_apply. */
+int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
+                          const float* gamma, const float* beta, const float* dsum, const void* gx_add,
+                          int32_t B, int32_t H, int32_t W, int32_t C, void* gx, int32_t cus, void* stream);
 /* head: pooled[b][c] = mean over (h,w) of relu(bn(x))  (post_activ + final_pool / avg_pool2d,
  * nbdt/models/resnet.py:142) and its backward given gpooled[B][C] (same two passes) */
 int nbdt_bn_relu_pool(const void* x, const float* save_mean, const float* save_rstd,

@@ -272,6 +272,69 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
   }
 }
 
+// The same pass on a FIXED NUMBER OF CUs (nbdt_bn_bwd_apply_cus): `cus` persistent blocks of up to 1024 threads,
+// one per CU (the launch asks for 96 KB of LDS it never touches, so a second block cannot join), two pixels in flight
+// per thread.  An HBM-bound pass needs few CUs -- 64 reach 3.0 TB/s, 96 4.1, all 256 5.6 (probes/cu_share_probe.hip) --
+// and an MFMA-bound kernel loses less than its share of CUs when it gives some up (the chip is power-limited: 192 CUs
+// deliver 83 % of the 256-CU matrix rate), so the weight gradient of the same unit runs on the other CUs meanwhile.
+// A block of the ordinary launch above is 4 waves and the dispatcher spreads 2048 of them over every CU, where
+// they keep an 8-wave weight-gradient block (a CU's whole register file) from starting at all.
+// Fused-ReLU form only (mask recomputed from x; what the engines' fused backward uses).
+template <bool HAS_ADD>
+__global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
+    const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ dsum, const bf16_t* __restrict__ gx_add, PadGeom g, int c8, int PY,
+    bf16_t* __restrict__ gx) {
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  if (py >= PY) return;
+  const float inv_n = 1.f / (float)g.npix;
+  float mu[8], rs[8], sh[8], k0[8], k1[8], sc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    sc[i] = gamma[c] * rs[i];
+    sh[i] = beta[c] - mu[i] * sc[i];
+    k0[i] = dsum[c] * inv_n;
+    k1[i] = dsum[g.C + c] * inv_n;
+  }
+  auto one = [&](const u32x4_t vx, const u32x4_t vg, const u32x4_t va, int o) {
+    float fx[8], fg[8], fa[8], out[8];
+    unpack8(vx, fx);
+    unpack8(vg, fg);
+    if (HAS_ADD) unpack8(va, fa);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (fx[i] - mu[i]) * rs[i];
+      const float gg = (fx[i] * sc[i] + sh[i]) > 0.f ? fg[i] : 0.f;
+      float v = sc[i] * (gg - k0[i] - xh * k1[i]);
+      if (HAS_ADD) v += fa[i];
+      out[i] = v;
+    }
+    *(u32x4_t*)(gx + o) = pack8(out);
+  };
+  const int step = gridDim.x * PY;
+  int p = blockIdx.x * PY + py;
+  for (; p + step < g.npix; p += 2 * step) {
+    const int o0 = pad_offset(g, p) + cx * 8, o1 = pad_offset(g, p + step) + cx * 8;
+    const u32x4_t x0 = *(const u32x4_t*)(x + o0), x1 = *(const u32x4_t*)(x + o1);
+    const u32x4_t g0 = *(const u32x4_t*)(gy + o0), g1 = *(const u32x4_t*)(gy + o1);
+    u32x4_t a0 = x0, a1 = x1;
+    if (HAS_ADD) { a0 = *(const u32x4_t*)(gx_add + o0); a1 = *(const u32x4_t*)(gx_add + o1); }
+    one(x0, g0, a0, o0);
+    one(x1, g1, a1, o1);
+  }
+  if (p < g.npix) {
+    const int o0 = pad_offset(g, p) + cx * 8;
+    const u32x4_t x0 = *(const u32x4_t*)(x + o0), g0 = *(const u32x4_t*)(gy + o0);
+    u32x4_t a0 = x0;
+    if (HAS_ADD) a0 = *(const u32x4_t*)(gx_add + o0);
+    one(x0, g0, a0, o0);
+  }
+}
+
 // pooled[b][c] = mean_hw relu(bn(x)); one thread per (b, 8-channel chunk)
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const bf16_t* __restrict__ x,
                                                            const float* __restrict__ mean,
@@ -513,6 +576,41 @@ extern "C" int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, c
     else { if (r) NBDT_BA(false, false, true); else NBDT_BA(false, false, false); }
   }
 #undef NBDT_BA
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
+                                    const float* gamma, const float* beta, const float* dsum, const void* gx_add,
+                                    int32_t B, int32_t H, int32_t W, int32_t C, void* gx, int32_t cus,
+                                    void* stream) {
+  NBDT_REQUIRE(gy && x && save_mean && save_rstd && gamma && beta && dsum && gx, "null argument");
+  NBDT_REQUIRE(cus >= 1 && cus <= 256, "cus must be 1..256");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  const PadGeom g = make_geom(B, H, W, C);
+  const int c8 = C / 8;
+  const int py = 1024 / c8;                       // C <= 2048 (check_shape): at least 4 pixel rows
+  constexpr int kForceLds = 96 * 1024;            // more than half a CU's LDS: one block per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    attr_set = true;
+  }
+  int blocks = cus;
+  const int max_blocks = (g.npix + py - 1) / py;
+  if (blocks > max_blocks) blocks = max_blocks;
+  const dim3 grid(blocks), blk(1024);
+  if (gx_add)
+    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true>), grid, blk, kForceLds, (hipStream_t)stream, (const bf16_t*)gy,
+                       (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, c8, py,
+                       (bf16_t*)gx);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false>), grid, blk, kForceLds, (hipStream_t)stream, (const bf16_t*)gy,
+                       (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, nullptr, g, c8, py, (bf16_t*)gx);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

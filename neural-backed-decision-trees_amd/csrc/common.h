@@ -104,6 +104,7 @@ int wgrad_dma(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw
 // wgrad_taps.hip: all-nine-taps weight-gradient kernel for dense 3x3 stride-1 convs (preferred)
 bool wgrad_taps_applicable(const nbdt_wgrad_desc* d);
 int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
+int wgrad_taps_blocks(const nbdt_wgrad_desc* d);   // blocks of the 8-wave launch (cu_budget applied), else 0
 
 // conv_dma.hip: LDS-DMA pipelined implicit GEMM (default path of nbdt_conv_igemm)
 struct BnBwdArgs {   // epilogue extras: the BatchNorm whose input gradient a dgrad launch produces (STATS mode 2)

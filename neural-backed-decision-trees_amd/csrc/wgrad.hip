@@ -27,12 +27,20 @@ extern "C" int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const vo
   NBDT_REQUIRE(d->x_bs % 8 == 0 && d->x_hs % 8 == 0 && d->x_ws % 8 == 0 && d->x_base % 8 == 0 &&
                d->g_bs % 8 == 0 && d->g_hs % 8 == 0 && d->g_ws % 8 == 0 && d->g_base % 8 == 0,
                "pixel offsets must be 16-byte aligned");
+  NBDT_REQUIRE(d->cu_budget == 0 || (d->cu_budget >= 32 && d->cu_budget <= 256), "cu_budget must be 0 or 32..256");
   const int64_t M_all = (int64_t)d->B * d->gh * d->gw;
   NBDT_REQUIRE(M_all < (1ll << 31), "pixel grid too large");
   if (nbdt::wgrad_taps_applicable(d)) return nbdt::wgrad_taps(d, x, gy, dw, (hipStream_t)stream);
   NBDT_REQUIRE(d->variant == 0, "variant 2 / 3 select between the dense 3x3 stride-1 kernels only");
   nbdt::g_last_wgrad = "conv_wgrad_dma_kernel";
   return nbdt::wgrad_dma(d, x, gy, dw, (hipStream_t)stream);
+}
+
+extern "C" int nbdt_conv_wgrad_blocks(const nbdt_wgrad_desc* d) {
+  if (!d || d->cin <= 0 || d->cin % 32 != 0 || d->cout <= 0 || d->cout % 32 != 0 || d->ntaps != 9) return 0;
+  if (d->B <= 0 || d->gh <= 0 || d->gw <= 0) return 0;
+  if (d->cu_budget != 0 && (d->cu_budget < 32 || d->cu_budget > 256)) return 0;
+  return nbdt::wgrad_taps_blocks(d);
 }
 
 namespace nbdt { thread_local const char* g_last_wgrad = ""; }

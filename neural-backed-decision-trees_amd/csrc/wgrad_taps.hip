@@ -642,13 +642,14 @@ static bool stage_geometry(const nbdt_wgrad_desc* d, int ks, int max_hp, WgradTa
 
 // PP: the 8-wave ping-pong kernel, 64-pixel stages, 1 block per CU (256 block slots); else 4-wave blocks,
 // 32-pixel stages, 2 per CU (512 slots)
-template <int WM, bool PP>
-static int launch_taps(WgradTapsParams& p, hipStream_t st) {
+// Pixel split of a launch: fills whole rounds of resident blocks from BELOW (513 items on 512 slots cost 40 %);
+// d.cu_budget: the caller wants only that many CUs filled (an HBM-bound pass on another stream gets the rest).
+static void split_items(WgradTapsParams& p, int wm, bool pp) {
   const nbdt_wgrad_desc& d = p.d;
   p.n_ci_blocks = d.cin / 32;
-  const int tiles = (d.cout / (32 * WM)) * p.n_ci_blocks;
-  // the split count fills whole rounds of resident blocks from BELOW (513 items on 512 slots cost 40 %)
-  int splits = (PP ? 256 : 512) / tiles;
+  const int tiles = (d.cout / (32 * wm)) * p.n_ci_blocks;
+  const int cus = d.cu_budget > 0 ? d.cu_budget : 256;
+  int splits = (pp ? cus : 2 * cus) / tiles;
   const int max_splits = p.stages / 16 > 0 ? p.stages / 16 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -657,6 +658,15 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   p.splits = splits;
   p.items = tiles * splits;
   p.per_xcd = (p.items + 7) / 8;
+}
+static int cout_tiles_wm(int cout) {
+  const int mt = cout / 32;
+  return mt % 5 == 0 ? 5 : (mt % 4 == 0 ? 4 : (mt % 2 == 0 ? 2 : 1));
+}
+
+template <int WM, bool PP>
+static int launch_taps(WgradTapsParams& p, hipStream_t st) {
+  split_items(p, WM, PP);
   const size_t shmem = PP ? (size_t)5 * (64 * 64 * WM + 144 * 64) : (size_t)NSTAGE * ((32 * WM / 8) * 512 + x_bytes(4));
   const void* fn = PP ? reinterpret_cast<const void*>(&conv_wgrad_pp_kernel<WM>)
                       : reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, 4>);
@@ -671,6 +681,26 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   return NBDT_OK;
 }
 
+// the 8-wave kernel: 64-pixel stages must tile the images (halo <= 144 slots) and a block needs a few dozen of
+// them to amortise its prologue; the 32-bit lane offsets of its DMA need tensors below 4 GiB
+static bool pp_fits_shape(const nbdt_wgrad_desc* d) {
+  return stage_geometry(d, 64, 144, nullptr) && (long long)d->B * d->x_bs * 2 < (1ll << 32) &&
+         (long long)d->B * d->g_bs * 2 < (1ll << 32);
+}
+static bool takes_pp(const nbdt_wgrad_desc* d, bool pp_fits) {
+  const long long M = (long long)d->B * d->gh * d->gw;
+  return pp_fits && (d->variant == 2 || (d->variant != 3 && M / 64 >= 32 * 8));
+}
+
+int wgrad_taps_blocks(const nbdt_wgrad_desc* d) {
+  if (!wgrad_taps_applicable(d) || !takes_pp(d, pp_fits_shape(d))) return 0;
+  WgradTapsParams p;
+  p.d = *d;
+  stage_geometry(d, 64, 144, &p);
+  split_items(p, cout_tiles_wm(d->cout), true);
+  return p.per_xcd * 8 < p.items ? p.per_xcd * 8 : p.items;
+}
+
 int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st) {
   WgradTapsParams p;
   p.d = *d;
@@ -678,13 +708,9 @@ int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* d
   p.gy = (const bf16_t*)gy;
   p.dw = dw;
   const int mt = d->cout / 32;
-  // the 8-wave kernel: 64-pixel stages must tile the images (halo <= 144 slots) and a block needs a few dozen of
-  // them to amortise its prologue; the 32-bit lane offsets of its DMA need tensors below 4 GiB
-  const long long M = (long long)d->B * d->gh * d->gw;
-  const bool pp_fits = stage_geometry(d, 64, 144, nullptr) && (long long)d->B * d->x_bs * 2 < (1ll << 32) &&
-                       (long long)d->B * d->g_bs * 2 < (1ll << 32);
+  const bool pp_fits = pp_fits_shape(d);
   NBDT_REQUIRE(!(d->variant == 2 && !pp_fits), "variant 2 (8-wave weight-gradient kernel): shape does not fit it");
-  const bool pp = pp_fits && (d->variant == 2 || (d->variant != 3 && M / 64 >= 32 * 8));
+  const bool pp = takes_pp(d, pp_fits);
   if (pp) {
     stage_geometry(d, 64, 144, &p);
     if (mt % 5 == 0) return launch_taps<5, true>(p, st);

@@ -47,6 +47,7 @@ class WgradDesc(ctypes.Structure):
         ("x_bs", c_int32), ("x_hs", c_int32), ("x_ws", c_int32), ("x_base", c_int32),
         ("g_bs", c_int32), ("g_hs", c_int32), ("g_ws", c_int32), ("g_base", c_int32),
         ("variant", c_int32),
+        ("cu_budget", c_int32),
     ]
 
 
@@ -64,6 +65,7 @@ SIGNATURES = {
     "nbdt_tree_max_depth": (c_int, [c_void_p]),
     "nbdt_debug_last_igemm": (c_char_p, []),
     "nbdt_debug_last_wgrad": (c_char_p, []),
+    "nbdt_conv_wgrad_blocks": (c_int, [_P]),
     "nbdt_soft_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P]),
     "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,
@@ -79,6 +81,7 @@ SIGNATURES = {
     "nbdt_conv_igemm_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm_affine": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "nbdt_bn_bwd_fold": (c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "nbdt_bn_bwd_apply_cus": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, _P]),
     "nbdt_conv_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
     "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_weight_prep_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),

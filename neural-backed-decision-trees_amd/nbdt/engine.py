@@ -155,7 +155,9 @@ class Conv:
         for d in descs:
             ops.conv_igemm(d, gout, self.wd, gin)
 
-    def backward_weight(self, x, gout):
+    def backward_weight(self, x, gout, cu_budget=0):
+        """cu_budget: CUs this launch is sized for when it runs on the second stream (0 = all of them): the caller
+        is about to launch an HBM-bound pass on the main stream that should get the remaining CUs."""
         B, Hp, Wp, _ = x.shape
         side = getattr(self, "side_stream", None)
         if side is None:
@@ -166,7 +168,7 @@ class Conv:
         main = torch.cuda.current_stream(x.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name))
+            ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name), cu_budget)
 
 
 class BatchNorm:
@@ -219,10 +221,12 @@ class BatchNorm:
     def apply(self, x, y, relu=True, residual=None):
         ops.bn_apply(x, self.mean, self.rstd, self.gamma, self.beta, y, relu=relu, residual=residual)
 
-    def backward_fused(self, gy, x, gx, partials, gx_add=None):
-        """Backward of relu(bn(x)) when the dgrad that produced gy already wrote the reduction partials."""
+    def backward_fused(self, gy, x, gx, partials, gx_add=None, cus=0):
+        """Backward of relu(bn(x)) when the dgrad that produced gy already wrote the reduction partials.
+        cus > 0: the elementwise pass is confined to that many CUs (a weight gradient runs on the others)."""
         ops.bn_bwd_fused(gy, x, self.mean, self.rstd, self.gamma, self.beta, partials, self.dsum,
-                         self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, gx_add=gx_add)
+                         self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, gx_add=gx_add,
+                         cus=cus)
 
     def backward(self, gy, y, x, gx, relu=True, gx_add=None, g_resid=None):
         """y=None: recompute the ReLU mask from x (valid when apply() had no residual)."""
@@ -248,6 +252,11 @@ class _Engine:
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
+        self._cu_share = None     # set_cu_share(): BatchNorm-backward passes beside weight gradients on disjoint CUs
+        self._share_join = False
+        self._share_calibrated = True
+        self.cu_share_report = None
+        self._overlap = True
 
     def scratch(self, C):
         need = ops.BN_SLOTS * 2 * C
@@ -284,6 +293,98 @@ class _Engine:
         for c in self.convs + list(getattr(self, "dws", [])):
             c.side_stream = self._side if on else None
         self._overlap = bool(on)
+
+    def set_cu_share(self, gbps_per_cu=47.0, target_us=200.0, min_cus=16, max_cus=96, join=False, calibrate=True):
+        """Run the BatchNorm-backward pass of every fused WRN unit BESIDE the weight gradient of the same conv, on
+        disjoint CUs (gbps_per_cu=None: off -- weight gradients next to the data gradients, every pass on all CUs).
+
+        Why it pays (probes/cu_share_probe.hip, profiles/r02_cu_share_probe.txt): the pass is HBM-bound and HBM needs
+        few CUs -- one CU streams ~47 GB/s, 64 CUs 3.0 TB/s, all 256 5.6 TB/s -- while the MFMA-bound weight gradient
+        loses LESS than its share of CUs when it gives some up, because the chip is power-limited (192 CUs deliver
+        83 % of the 256-CU matrix rate, and a streaming kernel on the other 64 does not slow them).  The two kernels
+        can never share a CU (a weight-gradient block takes its whole register file), so the split is by CU: the pass
+        runs as n persistent one-per-CU blocks (nbdt_bn_bwd_apply_cus), the weight gradient is sized for the rest
+        (nbdt_wgrad_desc.cu_budget).  n = bytes of the pass / (gbps_per_cu x target_us), clamped to
+        [min_cus, max_cus] and then set by the weight gradient's actual block count per XCD (_share_plan).
+        join: wait for the weight gradient before the next data gradient (bounds the cost of an unbalanced pair to
+        max(pass, weight gradient); measured 1 % slower when the pairs are balanced, so off by default).
+        calibrate: the first backward() times one stage-1 pair both ways on its own tensors (about a millisecond, once)
+        and turns the sharing off if the pair is not faster -- e.g. when the two streams were mapped to one hardware
+        queue and cannot overlap at all, where a pass confined to 50 CUs would cost 35 % of a step.
+        Only the second stream the engine was created with is used: streams created later wrapped onto the main
+        stream's hardware queue in one of four tries (measured), never the first one."""
+        self.join_side_stream()
+        self._cu_share = None if gbps_per_cu is None else (float(gbps_per_cu), float(target_us), int(min_cus), int(max_cus))
+        self._share_join = bool(join)
+        self._share_calibrated = not calibrate
+        self.cu_share_report = None
+
+    def _share_plan(self, conv, x, elements, tensors):
+        """(weight-gradient descriptor, its CU budget, CUs for the elementwise pass of `tensors` tensors of `elements`
+        bf16 that runs beside it)."""
+        gbps, us, lo, hi = self._cu_share
+        n = int(round(elements * 2 * tensors / (gbps * 1e9 * us * 1e-6)))
+        n = max(lo, min(hi, n))
+        B, Hp, Wp, _ = x.shape
+        desc = conv.plan(B, Hp - 2, Wp - 2)[3]
+        blocks = ops.conv_wgrad_blocks(desc, 256 - n)
+        if not 0 < blocks <= 256 - n:      # not the one-block-per-CU kernel (small problems): the model's n
+            return desc, 256 - n, n
+        # The weight gradient's pixel split is a whole number of blocks per (cout, cin) tile (205 blocks for a budget
+        # of 208; 160 for 232 with 80 tiles), and blocks go to the 8 XCDs round-robin by block index, per kernel: it
+        # puts ceil(blocks / 8) on each XCD, so the pass may take 32 minus that on EACH.  One block more on any XCD
+        # waits for a weight-gradient block to finish there -- the pass then takes as long as the weight gradient plus
+        # itself (measured: 19.1 -> 27 ms per step whenever the dispatch order fell that way).
+        return desc, 256 - n, 8 * (32 - (blocks + 7) // 8)
+
+    def _share_pair(self, conv, x, gout, elements, tensors):
+        """Issue conv's weight gradient on the second stream next to the pass that follows; returns the pass's CUs."""
+        _, budget, n = self._share_plan(conv, x, elements, tensors)
+        conv.backward_weight(x, gout, cu_budget=budget)
+        return n
+
+    def _calibrate_share(self, conv, x, gout, bn, gy, bx, gx, partials, elements, tensors):
+        """Time one (weight gradient, BatchNorm-backward pass) pair on its real operands: back to back on all CUs,
+        and side by side on disjoint CUs.  Every output goes to scratch (gx is rewritten by the real pass that
+        follows).  Turns the sharing off unless the pair is at least 5 % faster side by side."""
+        self._share_calibrated = True
+        desc, budget, n = self._share_plan(conv, x, elements, tensors)
+        main = torch.cuda.current_stream(self.device)
+        dw = torch.zeros_like(self.store.g(conv.name))
+        dsum = torch.empty(2 * bn.C, device=self.device)
+        dg, db = torch.zeros(bn.C, device=self.device), torch.zeros(bn.C, device=self.device)
+
+        def bn_pass(cus):
+            ops.bn_bwd_fused(gy, bx, bn.mean, bn.rstd, bn.gamma, bn.beta, partials, dsum, dg, db, gx, cus=cus)
+
+        def serial():
+            ops.conv_wgrad(desc, x, gout, dw, 0)
+            bn_pass(0)
+
+        def paired():
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                ops.conv_wgrad(desc, x, gout, dw, budget)
+            bn_pass(n)
+            main.wait_stream(self._side)
+
+        def best_us(fn):
+            best = float("inf")
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                fn()
+                e1.record(main)
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3)
+            return best
+
+        t_serial, t_pair = best_us(serial), best_us(paired)
+        keep = t_pair < 0.95 * t_serial
+        self.cu_share_report = {"pass_cus": n, "wgrad_cu_budget": budget, "serial_us": round(t_serial, 1),
+                                "side_by_side_us": round(t_pair, 1), "enabled": bool(keep)}
+        if not keep:
+            self._cu_share = None
 
     def join_side_stream(self):
         """Order every weight-gradient launch issued on the side stream before what follows on the main one."""
@@ -562,20 +663,46 @@ class WRNEngine(_Engine):
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             fuse = self.fuse_stats
-            u["conv2"].backward_weight(a2, g)
+            # CU sharing (set_cu_share): each weight gradient is issued AFTER the data gradient of its conv and sized
+            # for 256 - n CUs, and the BatchNorm-backward pass that follows on this stream is confined to n CUs, so
+            # the HBM-bound pass and the MFMA-bound kernel run at the same time on disjoint CUs.
+            share = self._cu_share is not None and fuse and self._side is not None and self._overlap
+            if share and not self._share_calibrated:
+                # the very first backward keeps the default order until it reaches a widest-tensor (stage-1) unit,
+                # calibrates the sharing on that unit's conv2 pair, and goes on with what the measurement says
+                share = u["idconv"] is None and u["cout"] == self.units[0]["cout"]
+            if not share:
+                u["conv2"].backward_weight(a2, g)
             if fuse:   # the dgrad epilogue also produces bn2's backward sums (ga2 is not re-read for them)
                 u["conv2"].backward_data(g, ga2, bn=u["bn2"], bn_x=t, partials=self.partials(t))
-                u["bn2"].backward_fused(ga2, t, gt, self.partials(t))
+                if share and not self._share_calibrated:
+                    self._calibrate_share(u["conv2"], a2, g, u["bn2"], ga2, t, gt, self.partials(t),
+                                          B * ho * wo * cout, 3)
+                    share = self._cu_share is not None
+                    if not share:       # the weight gradient the default order would have issued before the dgrad
+                        u["conv2"].backward_weight(a2, g)
+                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 3) if share else 0
+                u["bn2"].backward_fused(ga2, t, gt, self.partials(t), cus=n2)
+                if share and self._share_join:
+                    # The next data gradient is one persistent block per CU with a fixed share of the tiles: blocks
+                    # that found their CU still held by the weight gradient would start late and finish late, and
+                    # the delay would push the next weight gradient under the next data gradient, and so on (measured:
+                    # 19.1 -> 26 ms per step with the passes slightly too fast for the weight gradients).  Waiting
+                    # here makes an unbalanced pair cost max(pass, weight gradient), never more.
+                    self.join_side_stream()
             else:
                 u["conv2"].backward_data(g, ga2)
                 u["bn2"].backward(ga2, None, t, gt, relu=True)   # mask recomputed from t: a2 not re-read
-            u["conv1"].backward_weight(a1, gt)
             if fuse and u["idconv"] is None:
                 x_in = u["x_in"]
+                if not share:
+                    u["conv1"].backward_weight(a1, gt)
                 u["conv1"].backward_data(gt, ga1, bn=u["bn1"], bn_x=x_in, partials=self.partials(x_in))
-                u["bn1"].backward_fused(ga1, x_in, g_in, self.partials(x_in), gx_add=g)
+                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 4) if share else 0
+                u["bn1"].backward_fused(ga1, x_in, g_in, self.partials(x_in), gx_add=g, cus=n1)
                 g, h, w = g_in, hi, wi
-                continue
+                continue      # (the join at the top of the next unit orders this weight gradient)
+            u["conv1"].backward_weight(a1, gt)
             u["conv1"].backward_data(gt, ga1)
             if u["idconv"] is not None:
                 u["idconv"].backward_weight(a1, g)

@@ -220,16 +220,24 @@ def conv_igemm_affine(desc, inp, w_bf16, out, scale, shift, act=1, residual=None
                                        ptr(scale), ptr(shift), act, stream_ptr(inp.device)))
 
 
-def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, gx, gx_add=None):
-    """BatchNorm(+ReLU) backward when the producing dgrad already left the reduction partials."""
+def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, gx, gx_add=None, cus=0):
+    """BatchNorm(+ReLU) backward when the producing dgrad already left the reduction partials.
+    cus > 0: the apply pass runs on that many CUs only (nbdt_bn_bwd_apply_cus) -- the caller has a weight gradient
+    with cu_budget = 256 - cus in flight on another stream."""
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
     check(lib().nbdt_bn_bwd_fold(B, H, W, C, ptr(partials), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
+    if cus > 0:
+        check(lib().nbdt_bn_bwd_apply_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dsum),
+                                          ptr(gx_add), B, H, W, C, ptr(gx), int(cus), st))
+        return
     check(lib().nbdt_bn_bwd_apply(ptr(gy), None, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                                   ptr(dsum), ptr(gx_add), 1, B, H, W, C, ptr(gx), None, st))
 
 
-def conv_wgrad(desc, x, gy, dw):
+def conv_wgrad(desc, x, gy, dw, cu_budget=0):
+    """cu_budget: size the launch for that many CUs (0 = all) -- see nbdt_wgrad_desc.cu_budget."""
+    desc.cu_budget = int(cu_budget)
     ev = None
     if _timer is not None:
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
@@ -238,6 +246,13 @@ def conv_wgrad(desc, x, gy, dw):
     check(lib().nbdt_conv_wgrad(ctypes.byref(desc), ptr(x), ptr(gy), ptr(dw), stream_ptr(x.device)))
     if ev is not None:
         ev[1].record()
+
+
+def conv_wgrad_blocks(desc, cu_budget=0):
+    """Thread blocks (= CUs, for the 8-wave kernel) the weight-gradient launch of `desc` will use with that budget;
+    0 when the launch is not one of the CU-budgeted dense 3x3 kernels."""
+    desc.cu_budget = int(cu_budget)
+    return int(lib().nbdt_conv_wgrad_blocks(ctypes.byref(desc)))
 
 
 def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):

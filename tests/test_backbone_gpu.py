@@ -173,6 +173,89 @@ def test_dgrad_epilogue_bn_backward_sums(B, H, W, cin, cout):
     assert (gx_f.float() - gx_r.float()).abs().max().item() <= 2e-2 * gx_r.float().abs().max().item()
 
 
+@pytest.mark.parametrize("B,H,W,C", [(1, 4, 4, 16), (5, 16, 16, 24), (129, 16, 16, 160), (515, 32, 16, 320),
+                                     (512, 32, 32, 160), (3, 8, 8, 2048)])
+def test_partial_row_folds_match_a_plain_sum(B, H, W, C):
+    """nbdt_bn_finalize / nbdt_bn_bwd_fold on random [rows][2][C] partial rows (1, 5, 129, 1030, 2048 rows; one and
+    several channel blocks; the unrolled and the tail loop of the float4 fold) against an fp64 column sum."""
+    rows = (B * H * W + 255) // 256
+    g = torch.Generator().manual_seed(rows * 7 + C)
+    part = torch.randn(rows, 2, C, generator=g)
+    part[:, 1] = part[:, 1].abs() * 3 + part[:, 0] ** 2          # a plausible sum of squares (variance >= 0)
+    tot = part.double().sum(0)
+    n = float(B * H * W)
+    x = torch.empty(B, H + 2, W + 2, C, dtype=torch.bfloat16, device=DEV)       # shape carrier only (never read)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    ops.bn_finalize(x, part.to(DEV), mean, rstd, rm, rv)
+    m_ref = tot[0] / n
+    v_ref = (tot[1] / n - m_ref ** 2).clamp_min(0)
+    np.testing.assert_allclose(mean.cpu().double().numpy(), m_ref.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().double().numpy(), (v_ref + ops.BN_EPS).rsqrt().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(rm.cpu().double().numpy(), (ops.BN_MOMENTUM * m_ref).numpy(), rtol=2e-5, atol=1e-6)
+    unb = v_ref * n / (n - 1)
+    np.testing.assert_allclose(rv.cpu().double().numpy(), (1 - ops.BN_MOMENTUM + ops.BN_MOMENTUM * unb).numpy(), rtol=1e-4)
+    dsum, dg, db = torch.empty(2 * C, device=DEV), torch.ones(C, device=DEV), torch.full((C,), 2.0, device=DEV)
+    from nbdt._C import lib, ptr, check
+    check(lib().nbdt_bn_bwd_fold(B, H, W, C, ptr(part.to(DEV)), ptr(dsum), ptr(dg), ptr(db),
+                                 ops.stream_ptr(torch.device(DEV))))
+    scale = tot.abs().max().item()
+    np.testing.assert_allclose(dsum.cpu().double().numpy(), tot.reshape(-1).numpy(), rtol=2e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(db.cpu().double().numpy(), (tot[0] + 2).numpy(), rtol=2e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(dg.cpu().double().numpy(), (tot[1] + 1).numpy(), rtol=2e-5, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(64, 32, 32, 160), (8, 16, 16, 320), (3, 8, 8, 640), (2, 4, 4, 32), (1, 4, 4, 2048)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_batchnorm_backward_on_a_cu_subset_is_bit_identical(B, H, W, C, with_add):
+    """nbdt_bn_bwd_apply_cus (n persistent one-per-CU blocks, two pixels in flight per thread) writes exactly what
+    nbdt_bn_bwd_apply writes, for 1, 7, 48 and 256 CUs; the zero border stays zero."""
+    g = torch.Generator().manual_seed(B * 31 + C)
+    def act(scale):
+        p = ops.padded(B, H, W, C, DEV)
+        ops.interior(p).copy_((torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16).to(DEV))
+        return p
+    gy, x, add = act(1.0), act(2.0), act(1.0)
+    mean, rstd = (torch.randn(C, generator=g) * 0.1).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    part = torch.randn(((B * H * W + 255) // 256) * 2 * C, generator=g).to(DEV)
+    outs = []
+    for cus in (0, 1, 7, 48, 256):
+        dsum, dg, db = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        gx = ops.padded(B, H, W, C, DEV)
+        ops.bn_bwd_fused(gy, x, mean, rstd, gamma, beta, part, dsum, dg, db, gx, gx_add=add if with_add else None, cus=cus)
+        _check_border_zero(gx)
+        outs.append(gx)
+    assert outs[0].float().abs().max() > 0
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("B,H,W,C,expect", [(128, 32, 32, 160, {0: 250, 208: 205, 192: 190}),
+                                            (256, 16, 16, 320, {0: 240, 232: 220, 176: 160}),
+                                            (512, 8, 8, 640, {0: 240, 232: 160})])
+def test_weight_gradient_with_a_cu_budget(B, H, W, C, expect):
+    """nbdt_wgrad_desc.cu_budget only changes the pixel split of the 8-wave kernel (fp32 atomics in another order),
+    and nbdt_conv_wgrad_blocks tells the block count the engine's CU-sharing schedule plans with."""
+    g = torch.Generator().manual_seed(C)
+    d = ops.conv_wgrad_desc(B, H, W, C, C, 3, 1)
+    xp, gp = ops.padded(B, H, W, C, DEV), ops.padded(B, H, W, C, DEV)
+    ops.interior(xp).copy_(torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV))
+    ops.interior(gp).copy_(torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV))
+    ref = None
+    for budget, blocks in expect.items():
+        assert ops.conv_wgrad_blocks(d, budget) == blocks
+        dw = torch.zeros(C * 9 * C, device=DEV)
+        ops.conv_wgrad(d, xp, gp, dw, cu_budget=budget)
+        assert ops.last_wgrad_kernel() == "conv_wgrad_pp_kernel"
+        if ref is None:
+            ref = dw
+        else:
+            assert ((dw - ref).norm() / ref.norm()).item() < 2e-6
+    with pytest.raises(Exception):
+        ops.conv_wgrad(d, xp, gp, torch.zeros(C * 9 * C, device=DEV), cu_budget=8)
+
+
 def test_conv_identity_weights_are_transpose_detecting():
     # w[co][center][ci] = 1 if co == perm(ci): output channel co must equal input channel perm^-1(co)
     B, H, W, C = 2, 8, 8, 160

@@ -21,6 +21,8 @@ from nbdt import engine as E  # noqa: E402
 from nbdt.loss import SoftTreeSupLoss  # noqa: E402
 
 DEV = "cuda:0"
+# thresholds of test_bench_configuration_step_matches_fp32_oracle (measured values in its docstring / DESIGN.md)
+BENCH_CFG_MIN_ARGMAX, BENCH_CFG_MIN_COS, BENCH_CFG_MAX_NORM_DEV = 0.9, 0.9, 0.2
 
 
 def _rel_l2(a, b):
@@ -250,6 +252,110 @@ def test_wrn28_10_full_size_step_runs():
         l1 = E.train_step(eng, crit, x, y, lr=0.02).item()
     assert math.isfinite(l0) and math.isfinite(l1) and l1 < l0, (l0, l1)
     assert torch.isfinite(eng.store.flat).all()
+
+
+def test_bench_configuration_step_matches_fp32_oracle(pkg_dir):
+    """The configuration bench.py times -- WRN-28-10, 512 CIFAR10-shaped images, SoftTreeSupLoss on the
+    induced-wrn28_10_cifar10 hierarchy -- one train-mode forward + loss + backward against the fp32 CPU oracle port
+    with identical weights and inputs (about half a minute of host time).  Every dense 3x3 launch here takes the
+    8-wave ping-pong kernels with 4 / 2 / 1 tiles per persistent block, the data gradients their BatchNorm-backward
+    epilogue and the weight gradients the 8-wave kernel, exactly as in the timed step (test_bench_shape_conv_forward_dgrad_wgrad asserts the kernel names at these shapes).  Tolerances as in the small
+    tests above: bf16 storage against fp32 arithmetic; the hard decisions of each path's rules on its own logits are
+    compared on top (HIP kernel vs numpy oracle)."""
+    import psutil
+    from nbdt import _C
+    from nbdt.tree import Tree
+    B = 512
+    if psutil.virtual_memory().available < 48 << 30:     # the fp32 autograd graph of 512 images is ~25 GB of host RAM
+        pytest.skip("needs 48 GB of free host memory for the CPU oracle")
+    ref, eng = _pair(28, 10, 10)
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (B,), generator=g)
+    ref.train()
+    z_ref, loss_ref = _oracle_loss_backward(ref, otree, x, y)
+
+    eng.zero_grad()
+    z = eng.forward(x.to(DEV), training=True)
+    loss, gz = crit.loss_and_grad(z, y.to(DEV))
+    eng.backward(gz)
+    torch.cuda.synchronize()
+
+    scale = z_ref.abs().max().item()
+    err = (z.cpu() - z_ref).abs().max().item()
+    agree = (z.cpu().argmax(1) == z_ref.argmax(1)).float().mean().item()
+    tree = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
+    hard = _C.hard_forward(tree.device_handle(0), z.float(), want_onehot=False)[0].cpu().numpy()
+    hard_ref = O.hard_forward(otree, z_ref.numpy())
+    hard_agree = float((hard == hard_ref).mean())
+    print(f"logit err {err:.4g} of scale {scale:.4g}; loss {loss.item():.5f} vs {loss_ref:.5f}; "
+          f"argmax agreement {agree:.4f}; hard-decision agreement {hard_agree:.4f}")
+    grads = eng.named_params("grad")
+    report, worst_cos, worst_ratio = [], 1.0, 0.0
+    for name, p in ref.named_parameters():
+        c = _cos(grads[name], p.grad)
+        ratio = grads[name].float().norm().item() / p.grad.norm().item()
+        report.append(f"cos {c:.4f} norm-ratio {ratio:.4f} {name}")
+        worst_cos = min(worst_cos, c)
+        worst_ratio = max(worst_ratio, abs(ratio - 1))
+    print("\n".join(report))
+    print(f"worst gradient cosine {worst_cos:.4f}, worst norm deviation {worst_ratio:.4f}")
+    assert err < 3e-2 * scale, (err, scale)
+    assert abs(loss.item() - loss_ref) < 2e-2 * abs(loss_ref)
+    assert agree >= BENCH_CFG_MIN_ARGMAX and hard_agree >= BENCH_CFG_MIN_ARGMAX, (agree, hard_agree)
+    assert worst_cos > BENCH_CFG_MIN_COS and worst_ratio < BENCH_CFG_MAX_NORM_DEV, (worst_cos, worst_ratio)
+
+
+def test_cu_sharing_schedule_trains_like_the_default_one():
+    """engine.set_cu_share: BatchNorm-backward passes on a CU subset beside CU-budgeted weight gradients.  Both
+    kernels are exact twins of the default ones (test_backbone_gpu.py), so the schedule may only change the order of
+    fp32 atomics: same loss trajectory as the default order on WRN-28-10 (batch 128: every 3x3 conv takes the 8-wave
+    kernels the schedule plans with), calibration report filled in, the default order restored by None."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(128, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (128,), generator=g).to(DEV)
+    runs = {}
+    for mode in ("default", "share", "share+join"):
+        eng = E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=4)
+        if mode != "default":
+            eng.set_cu_share(47.0, join=(mode == "share+join"))
+        losses = []
+        for i in range(4):
+            if mode != "default" and i == 1:      # whatever the calibration decided, exercise the schedule
+                eng.set_cu_share(47.0, join=(mode == "share+join"), calibrate=False)
+            losses.append(E.train_step(eng, crit, x, y, lr=0.02).item())
+        runs[mode] = losses
+        if mode == "share":
+            eng.set_cu_share(None)
+            assert math.isfinite(E.train_step(eng, crit, x, y, lr=0.02).item())
+    print(runs)
+    for mode in ("share", "share+join"):
+        for a, b in zip(runs[mode], runs["default"]):
+            assert abs(a - b) < 2e-2 * abs(b), runs
+        assert runs[mode][-1] < runs[mode][0]
+
+
+def test_cu_sharing_calibration_reports_one_pair():
+    eng = E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=4)
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(128, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (128,), generator=g).to(DEV)
+    eng.set_cu_share(47.0)
+    assert eng.cu_share_report is None
+    E.train_step(eng, crit, x, y, lr=0.02)
+    rep = eng.cu_share_report
+    print(rep)
+    assert rep is not None and rep["pass_cus"] % 8 == 0 and 8 <= rep["pass_cus"] <= 96
+    assert rep["pass_cus"] + rep["wgrad_cu_budget"] <= 256 + 8
+    assert rep["serial_us"] > 0 and rep["side_by_side_us"] > 0
+    assert rep["enabled"] == (eng._cu_share is not None)
 
 
 def test_hipgraph_captured_step_equals_eager_steps():

@@ -22,7 +22,7 @@ from nbdt.loss import SoftTreeSupLoss  # noqa: E402
 
 DEV = "cuda:0"
 # thresholds of test_bench_configuration_step_matches_fp32_oracle (measured values in its docstring / DESIGN.md)
-BENCH_CFG_MIN_ARGMAX, BENCH_CFG_MIN_COS, BENCH_CFG_MAX_NORM_DEV = 0.9, 0.9, 0.2
+BENCH_CFG_MIN_ARGMAX, BENCH_CFG_MIN_COS, BENCH_CFG_MAX_NORM_DEV = 0.97, 0.87, 0.25
 
 
 def _rel_l2(a, b):
@@ -261,7 +261,11 @@ def test_bench_configuration_step_matches_fp32_oracle(pkg_dir):
     8-wave ping-pong kernels with 4 / 2 / 1 tiles per persistent block, the data gradients their BatchNorm-backward
     epilogue and the weight gradients the 8-wave kernel, exactly as in the timed step (test_bench_shape_conv_forward_dgrad_wgrad asserts the kernel names at these shapes).  Tolerances as in the small
     tests above: bf16 storage against fp32 arithmetic; the hard decisions of each path's rules on its own logits are
-    compared on top (HIP kernel vs numpy oracle)."""
+    compared on top (HIP kernel vs numpy oracle).  Measured (profiles/r02_bench_config_parity.txt): logits within
+    1.35 % of their scale, loss 4.64159 vs 4.64163, argmax agreement 0.990, hard decisions 1.000, gradient cosine
+    0.986 at the last conv falling to 0.91-0.93 at the first (ReLU-mask flips of 1-ulp bf16 differences accumulate
+    over 25 layers; two runs of the engine itself differ by as much), conv-weight gradient norms within 0.4 %, the
+    16- to 640-element BatchNorm gradients within 6-17 % by run (hence 25 % for those)."""
     import psutil
     from nbdt import _C
     from nbdt.tree import Tree
@@ -301,6 +305,8 @@ def test_bench_configuration_step_matches_fp32_oracle(pkg_dir):
         report.append(f"cos {c:.4f} norm-ratio {ratio:.4f} {name}")
         worst_cos = min(worst_cos, c)
         worst_ratio = max(worst_ratio, abs(ratio - 1))
+        if name.endswith("conv.weight"):      # 36.5 M of the 36.5 M parameters: norms within 2 % (measured 0.4 %)
+            assert abs(ratio - 1) < 0.02, report[-1]
     print("\n".join(report))
     print(f"worst gradient cosine {worst_cos:.4f}, worst norm deviation {worst_ratio:.4f}")
     assert err < 3e-2 * scale, (err, scale)

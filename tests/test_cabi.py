@@ -40,6 +40,29 @@ def test_argument_validation_without_gpu():
     assert lib.nbdt_conv_igemm(d, None, None, None, None, None) == -1
 
 
+def test_weight_gradient_block_count_query_is_host_only():
+    """nbdt_conv_wgrad_blocks (what engine.set_cu_share plans the CU split with) does no device work: the pixel
+    split of the 8-wave kernel for the three WRN-28-10 stage shapes at 512 images, with and without a CU budget;
+    0 for launches that take another kernel; blocks never exceed a budget of at least one block per tile; and the ctypes mirror of
+    nbdt_wgrad_desc has the header's layout (35 int32)."""
+    import ctypes
+    from nbdt import ops
+    assert ctypes.sizeof(_C.WgradDesc) == 35 * 4
+    expect = {(512, 32, 32, 160): {0: 255, 208: 205, 202: 200, 185: 185},
+              (512, 16, 16, 320): {0: 240, 229: 220, 220: 220, 216: 200},
+              (512, 8, 8, 640): {0: 240, 240: 240, 238: 160}}
+    for (B, H, W, C), table in expect.items():
+        d = ops.conv_wgrad_desc(B, H, W, C, C, 3, 1)
+        for budget, blocks in table.items():
+            assert ops.conv_wgrad_blocks(d, budget) == blocks, (B, H, W, C, budget)
+        for budget in range(96, 257, 7):     # (below one block per (cout, cin) tile -- 80 in stage 3 -- there is no split left)
+            assert 0 < ops.conv_wgrad_blocks(d, budget) <= budget
+        assert ops.conv_wgrad_blocks(d, 8) == 0                     # not a valid budget
+    assert ops.conv_wgrad_blocks(ops.conv_wgrad_desc(16, 8, 8, 640, 640, 3, 1), 0) == 0    # too few pixels: 4-wave kernel
+    assert ops.conv_wgrad_blocks(ops.conv_wgrad_desc(512, 32, 32, 160, 320, 3, 2), 208) == 0  # strided: other kernel
+    assert ops.conv_wgrad_blocks(ops.conv_wgrad_desc(512, 32, 32, 160, 320, 1, 1), 208) == 0  # 1x1
+
+
 def test_product_path_refuses_cpu_tensors():
     from nbdt.loss import SoftTreeSupLoss
     from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules

@@ -257,6 +257,13 @@ int nbdt_bn_bwd_apply(const void* gy, const void* y, const void* x, const float*
 int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
                           const float* gamma, const float* beta, const float* dsum, const void* gx_add,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* gx, int32_t cus, void* stream);
+/* nbdt_bn_bwd_reduce with relu = 1, y = NULL on `cus` CUs only (see nbdt_bn_bwd_apply_cus): with it the sums need not
+ * come out of the data gradient's epilogue (nbdt_conv_igemm_bnbwd), and the whole BatchNorm backward -- reduce, fold,
+ * apply -- is HBM-bound work that runs beside the weight gradient.  scratch: the zeroed 32-slot buffer of
+ * nbdt_bn_bwd_reduce (left zeroed). */
+int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
+                           const float* gamma, const float* beta, int32_t B, int32_t H, int32_t W, int32_t C,
+                           float* scratch, float* dsum, float* dgamma, float* dbeta, int32_t cus, void* stream);
 /* head: pooled[b][c] = mean over (h,w) of relu(bn(x))  (post_activ + final_pool / avg_pool2d,
  * nbdt/models/resnet.py:142) and its backward given gpooled[B][C] (same two passes) */
 int nbdt_bn_relu_pool(const void* x, const float* save_mean, const float* save_rstd,

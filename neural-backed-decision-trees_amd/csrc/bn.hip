@@ -335,6 +335,76 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
   }
 }
 
+// Reduction twin of bn_bwd_apply_cus_kernel: sum g', sum g'*xhat of relu(bn(x))'s backward on `cus` persistent
+// one-per-CU blocks (same thread layout, two pixels in flight), folded per block through the (otherwise only
+// occupancy-forcing) dynamic LDS and added to the 32 replicated slots of `scratch` like bn_bwd_reduce_kernel does.
+// With it the BatchNorm-backward sums no longer have to come out of the data gradient's epilogue, which reads the
+// BatchNorm input in an HBM burst while the matrix pipes wait (+50 us per launch at 32x32x160): the whole
+// BatchNorm backward (reduce, fold, apply) becomes HBM-bound work beside the weight gradient.
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* __restrict__ gy,
+                                                                 const bf16_t* __restrict__ x,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, PadGeom g, int c8,
+                                                                 int PY, float* __restrict__ scratch) {
+  extern __shared__ float lds[];
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  const bool live = py < PY;               // (threads past the last whole pixel row idle, but join the block fold)
+  float mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (live ? cx : 0) * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    sc[i] = gamma[c] * rs[i];
+    sh[i] = beta[c] - mu[i] * sc[i];
+  }
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+  auto one = [&](const u32x4_t vx, const u32x4_t vg) {
+    float fx[8], fg[8];
+    unpack8(vx, fx);
+    unpack8(vg, fg);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (fx[i] - mu[i]) * rs[i];
+      const float gg = (fx[i] * sc[i] + sh[i]) > 0.f ? fg[i] : 0.f;
+      acc[0][i] += gg;
+      acc[1][i] += gg * xh;
+    }
+  };
+  if (live) {
+    const int step = gridDim.x * PY;
+    int p = blockIdx.x * PY + py;
+    for (; p + step < g.npix; p += 2 * step) {
+      const int o0 = pad_offset(g, p) + cx * 8, o1 = pad_offset(g, p + step) + cx * 8;
+      const u32x4_t x0 = *(const u32x4_t*)(x + o0), x1 = *(const u32x4_t*)(x + o1);
+      const u32x4_t g0 = *(const u32x4_t*)(gy + o0), g1 = *(const u32x4_t*)(gy + o1);
+      one(x0, g0);
+      one(x1, g1);
+    }
+    if (p < g.npix) {
+      const int o0 = pad_offset(g, p) + cx * 8;
+      one(*(const u32x4_t*)(x + o0), *(const u32x4_t*)(gy + o0));
+    }
+  }
+  // block fold: [PY][c8][16] floats in LDS, then one atomic per (channel, sum) of the block into its slot
+  if (live) {
+    float* mine = lds + ((size_t)py * c8 + cx) * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mine[i] = acc[0][i]; mine[8 + i] = acc[1][i]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < c8 * 16; e += 1024) {
+    const int ccx = e >> 4, k = e & 15;
+    float s = 0.f;
+    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + ccx) * 16 + k];
+    atomicAdd(scratch + ((size_t)(blockIdx.x & (kSlots - 1)) * 2 + (k >> 3)) * g.C + ccx * 8 + (k & 7), s);
+  }
+}
+
 // pooled[b][c] = mean_hw relu(bn(x)); one thread per (b, 8-channel chunk)
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const bf16_t* __restrict__ x,
                                                            const float* __restrict__ mean,
@@ -611,6 +681,36 @@ extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float*
   else
     hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false>), grid, blk, kForceLds, (hipStream_t)stream, (const bf16_t*)gy,
                        (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, nullptr, g, c8, py, (bf16_t*)gx);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
+                                     const float* gamma, const float* beta, int32_t B, int32_t H, int32_t W,
+                                     int32_t C, float* scratch, float* dsum, float* dgamma, float* dbeta,
+                                     int32_t cus, void* stream) {
+  NBDT_REQUIRE(gy && x && save_mean && save_rstd && gamma && beta && scratch && dsum, "null argument");
+  NBDT_REQUIRE(cus >= 1 && cus <= 256, "cus must be 1..256");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const int c8 = C / 8;
+  const int py = 1024 / c8;
+  constexpr int kForceLds = 96 * 1024;            // one block per CU; the block fold uses py*c8*64 <= 64 KB of it
+  static bool attr_set = false;
+  if (!attr_set) {
+    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    attr_set = true;
+  }
+  int blocks = cus;
+  const int max_blocks = (g.npix + py - 1) / py;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(bn_bwd_reduce_cus_kernel, dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, scratch);
+  NBDT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

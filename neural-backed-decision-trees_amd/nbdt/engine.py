@@ -228,6 +228,11 @@ class BatchNorm:
                          self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, gx_add=gx_add,
                          cus=cus)
 
+    def backward_cus(self, gy, x, gx, cus, gx_add=None):
+        """Backward of relu(bn(x)) entirely on `cus` CUs: sums, fold and elementwise pass (no dgrad-epilogue partials)."""
+        ops.bn_bwd_cus(gy, x, self.mean, self.rstd, self.gamma, self.beta, self.owner.scratch(self.C), self.dsum,
+                       self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, cus, gx_add=gx_add)
+
     def backward(self, gy, y, x, gx, relu=True, gx_add=None, g_resid=None):
         """y=None: recompute the ReLU mask from x (valid when apply() had no residual)."""
         ops.bn_bwd(gy, y, x, self.mean, self.rstd, self.gamma, self.owner.scratch(self.C), self.dsum,
@@ -254,6 +259,7 @@ class _Engine:
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
         self._cu_share = None     # set_cu_share(): BatchNorm-backward passes beside weight gradients on disjoint CUs
         self._share_join = False
+        self._share_split = (False, 250.0)
         self._share_calibrated = True
         self.cu_share_report = None
         self._overlap = True
@@ -294,7 +300,8 @@ class _Engine:
             c.side_stream = self._side if on else None
         self._overlap = bool(on)
 
-    def set_cu_share(self, gbps_per_cu=47.0, target_us=200.0, min_cus=16, max_cus=96, join=False, calibrate=True):
+    def set_cu_share(self, gbps_per_cu=47.0, target_us=200.0, min_cus=16, max_cus=128, join=False, calibrate=True,
+                     split_reduce=True, split_target_us=190.0):
         """Run the BatchNorm-backward pass of every fused WRN unit BESIDE the weight gradient of the same conv, on
         disjoint CUs (gbps_per_cu=None: off -- weight gradients next to the data gradients, every pass on all CUs).
 
@@ -306,6 +313,11 @@ class _Engine:
         runs as n persistent one-per-CU blocks (nbdt_bn_bwd_apply_cus), the weight gradient is sized for the rest
         (nbdt_wgrad_desc.cu_budget).  n = bytes of the pass / (gbps_per_cu x target_us), clamped to
         [min_cus, max_cus] and then set by the weight gradient's actual block count per XCD (_share_plan).
+        split_reduce: the BatchNorm-backward SUMS move there too -- the data gradients run with their plain epilogue
+        (the fused one reads the BatchNorm input in an HBM burst while the matrix pipes wait: 240 instead of 190 us
+        per stage-1 launch) and the confined work becomes reduce + fold + apply (nbdt_bn_bwd_reduce_cus +
+        nbdt_bn_bwd_apply_cus: 5-6 tensor passes instead of 3-4, so n is larger: split_target_us).  Same-box A/B at
+        512 images: 19.30 ms per step without sharing, 18.37 with the fused sums, 17.73 with the split.
         join: wait for the weight gradient before the next data gradient (bounds the cost of an unbalanced pair to
         max(pass, weight gradient); measured 1 % slower when the pairs are balanced, so off by default).
         calibrate: the first backward() times one stage-1 pair both ways on its own tensors (about a millisecond, once)
@@ -316,13 +328,15 @@ class _Engine:
         self.join_side_stream()
         self._cu_share = None if gbps_per_cu is None else (float(gbps_per_cu), float(target_us), int(min_cus), int(max_cus))
         self._share_join = bool(join)
+        self._share_split = bool(split_reduce), float(split_target_us)
         self._share_calibrated = not calibrate
         self.cu_share_report = None
 
-    def _share_plan(self, conv, x, elements, tensors):
+    def _share_plan(self, conv, x, elements, tensors, us=None):
         """(weight-gradient descriptor, its CU budget, CUs for the elementwise pass of `tensors` tensors of `elements`
         bf16 that runs beside it)."""
-        gbps, us, lo, hi = self._cu_share
+        gbps, us0, lo, hi = self._cu_share
+        us = us0 if us is None else us
         n = int(round(elements * 2 * tensors / (gbps * 1e9 * us * 1e-6)))
         n = max(lo, min(hi, n))
         B, Hp, Wp, _ = x.shape
@@ -337,9 +351,9 @@ class _Engine:
         # itself (measured: 19.1 -> 27 ms per step whenever the dispatch order fell that way).
         return desc, 256 - n, 8 * (32 - (blocks + 7) // 8)
 
-    def _share_pair(self, conv, x, gout, elements, tensors):
+    def _share_pair(self, conv, x, gout, elements, tensors, us=None):
         """Issue conv's weight gradient on the second stream next to the pass that follows; returns the pass's CUs."""
-        _, budget, n = self._share_plan(conv, x, elements, tensors)
+        _, budget, n = self._share_plan(conv, x, elements, tensors, us)
         conv.backward_weight(x, gout, cu_budget=budget)
         return n
 
@@ -673,7 +687,16 @@ class WRNEngine(_Engine):
                 share = u["idconv"] is None and u["cout"] == self.units[0]["cout"]
             if not share:
                 u["conv2"].backward_weight(a2, g)
-            if fuse:   # the dgrad epilogue also produces bn2's backward sums (ga2 is not re-read for them)
+            split = share and self._share_calibrated and self._share_split[0]
+            if split:
+                # the BatchNorm-backward sums move out of the data gradient's epilogue (which reads the BatchNorm input
+                # in an HBM burst while the matrix pipes wait) into the CU-confined pass beside the weight gradient
+                u["conv2"].backward_data(g, ga2)
+                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 5, self._share_split[1])
+                u["bn2"].backward_cus(ga2, t, gt, n2)
+                if self._share_join:
+                    self.join_side_stream()
+            elif fuse:   # the dgrad epilogue also produces bn2's backward sums (ga2 is not re-read for them)
                 u["conv2"].backward_data(g, ga2, bn=u["bn2"], bn_x=t, partials=self.partials(t))
                 if share and not self._share_calibrated:
                     self._calibrate_share(u["conv2"], a2, g, u["bn2"], ga2, t, gt, self.partials(t),
@@ -693,6 +716,13 @@ class WRNEngine(_Engine):
             else:
                 u["conv2"].backward_data(g, ga2)
                 u["bn2"].backward(ga2, None, t, gt, relu=True)   # mask recomputed from t: a2 not re-read
+            if split and u["idconv"] is None:
+                x_in = u["x_in"]
+                u["conv1"].backward_data(gt, ga1)
+                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 6, self._share_split[1])
+                u["bn1"].backward_cus(ga1, x_in, g_in, n1, gx_add=g)
+                g, h, w = g_in, hi, wi
+                continue
             if fuse and u["idconv"] is None:
                 x_in = u["x_in"]
                 if not share:

@@ -235,6 +235,17 @@ def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, 
                                   ptr(dsum), ptr(gx_add), 1, B, H, W, C, ptr(gx), None, st))
 
 
+def bn_bwd_cus(gy, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx, cus, gx_add=None):
+    """Whole BatchNorm(+ReLU) backward -- sums, fold, elementwise pass -- on `cus` CUs (no partials from a dgrad
+    epilogue needed): nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus."""
+    B, H, W, C = _dims(x)
+    st = stream_ptr(x.device)
+    check(lib().nbdt_bn_bwd_reduce_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, H, W, C,
+                                       ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), int(cus), st))
+    check(lib().nbdt_bn_bwd_apply_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dsum),
+                                      ptr(gx_add), B, H, W, C, ptr(gx), int(cus), st))
+
+
 def conv_wgrad(desc, x, gy, dw, cu_budget=0):
     """cu_budget: size the launch for that many CUs (0 = all) -- see nbdt_wgrad_desc.cu_budget."""
     desc.cu_budget = int(cu_budget)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of engine.set_cu_share on the bench workload (WRN-28-10, B=512): ms/step with the BatchNorm-backward passes
 confined to n CUs beside the weight gradients, for a list of settings, alternating, one process.
-usage: cu_share_ab.py [--steps 40] [--rounds 2] setting ...   setting = off | gbps:target_us:min:max[:join]"""
+usage: cu_share_ab.py [--steps 40] [--rounds 2] setting ...   setting = off | gbps:target_us:min:max[:join][:split<target_us>]"""
 import argparse
 import os
 import sys
@@ -36,7 +36,9 @@ def apply(setting):
         return
     f = setting.split(":")
     flags = f[4] if len(f) > 4 else ""
-    eng.set_cu_share(float(f[0]), float(f[1]), int(f[2]), int(f[3]), join=("join" in flags), calibrate=False)
+    split_us = [float(x[5:]) for x in flags.split("-") if x.startswith("split")]
+    eng.set_cu_share(float(f[0]), float(f[1]), int(f[2]), int(f[3]), join=("join" in flags), calibrate=False,
+                     split_reduce=bool(split_us), split_target_us=split_us[0] if split_us else 250.0)
 
 
 # gradients of one step: share on vs off (same weights, same batch): equal up to the order of fp32 atomics

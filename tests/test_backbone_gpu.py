@@ -231,6 +231,42 @@ def test_batchnorm_backward_on_a_cu_subset_is_bit_identical(B, H, W, C, with_add
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("B,H,W,C", [(64, 32, 32, 160), (8, 16, 16, 320), (3, 8, 8, 640), (2, 4, 4, 32), (1, 4, 4, 2048)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_whole_batchnorm_backward_on_a_cu_subset(B, H, W, C, with_add):
+    """nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus (sums, fold and elementwise pass on n one-per-CU blocks) against
+    the ordinary nbdt_bn_bwd_reduce + nbdt_bn_bwd_apply: same sums up to fp32 summation order, the same input
+    gradient up to one bf16 rounding of values that depend on those sums; slots left zeroed; 1, 7, 48, 256 CUs."""
+    g = torch.Generator().manual_seed(B * 17 + C)
+    def act(scale):
+        p = ops.padded(B, H, W, C, DEV)
+        ops.interior(p).copy_((torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16).to(DEV))
+        return p
+    gy, x, add = act(1.0), act(2.0), act(1.0)
+    mean, rstd = (torch.randn(C, generator=g) * 0.1).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * 2048, device=DEV)
+    def run(cus):
+        dsum, dg, db = torch.empty(2 * C, device=DEV), torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+        gx = ops.padded(B, H, W, C, DEV)
+        if cus == 0:
+            ops.bn_bwd(gy, None, x, mean, rstd, gamma, scratch, dsum, dg, db, gx, relu=True,
+                       gx_add=add if with_add else None, beta=beta)
+        else:
+            ops.bn_bwd_cus(gy, x, mean, rstd, gamma, beta, scratch, dsum, dg, db, gx, cus, gx_add=add if with_add else None)
+        assert scratch.abs().max().item() == 0
+        _check_border_zero(gx)
+        return dsum, dg, db, gx.float()
+    ref = run(0)
+    scale = ref[0].abs().max().item()
+    for cus in (1, 7, 48, 256):
+        got = run(cus)
+        for a, b in zip(got[:3], ref[:3]):
+            assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-5, cus
+        tol = 2.0 ** -7 * ref[3].abs() + 1e-3 * ref[3].abs().mean()
+        assert ((got[3] - ref[3]).abs() <= tol).all(), cus
+
+
 @pytest.mark.parametrize("B,H,W,C,expect", [(128, 32, 32, 160, {0: 250, 208: 205, 192: 190}),
                                             (256, 16, 16, 320, {0: 240, 232: 220, 176: 160}),
                                             (512, 8, 8, 640, {0: 240, 232: 160})])

@@ -677,6 +677,12 @@ class WRNEngine(_Engine):
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             fuse = self.fuse_stats
+            if (self._cu_share is not None and self._share_split[0] and self._share_calibrated
+                    and not (self._side is not None and self._overlap)):
+                # one-stream mode (profiling passes, bench.py's roofline pass) of the split schedule: the same kernels
+                # as the timed step -- data gradients with their plain epilogue, BatchNorm sums in a pass of their
+                # own -- back to back on all CUs
+                fuse = False
             # CU sharing (set_cu_share): each weight gradient is issued AFTER the data gradient of its conv and sized
             # for 256 - n CUs, and the BatchNorm-backward pass that follows on this stream is confined to n CUs, so
             # the HBM-bound pass and the MFMA-bound kernel run at the same time on disjoint CUs.

@@ -396,7 +396,9 @@ class _Engine:
         t_serial, t_pair = best_us(serial), best_us(paired)
         keep = t_pair < 0.95 * t_serial
         self.cu_share_report = {"pass_cus": n, "wgrad_cu_budget": budget, "serial_us": round(t_serial, 1),
-                                "side_by_side_us": round(t_pair, 1), "enabled": bool(keep)}
+                                "side_by_side_us": round(t_pair, 1), "enabled": bool(keep),
+                                "bn_sums": "beside the weight gradient (nbdt_bn_bwd_reduce_cus)" if self._share_split[0]
+                                           else "data-gradient epilogue"}
         if not keep:
             self._cu_share = None
 

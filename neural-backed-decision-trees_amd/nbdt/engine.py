@@ -679,7 +679,7 @@ class WRNEngine(_Engine):
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             fuse = self.fuse_stats
-            if (self._cu_share is not None and self._share_split[0] and self._share_calibrated
+            if (self._cu_share is not None and self._share_split[0]
                     and not (self._side is not None and self._overlap)):
                 # one-stream mode (profiling passes, bench.py's roofline pass) of the split schedule: the same kernels
                 # as the timed step -- data gradients with their plain epilogue, BatchNorm sums in a pass of their

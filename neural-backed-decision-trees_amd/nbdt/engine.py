@@ -336,20 +336,10 @@ class _Engine:
         """(weight-gradient descriptor, its CU budget, CUs for the elementwise pass of `tensors` tensors of `elements`
         bf16 that runs beside it)."""
         gbps, us0, lo, hi = self._cu_share
-        us = us0 if us is None else us
-        n = int(round(elements * 2 * tensors / (gbps * 1e9 * us * 1e-6)))
-        n = max(lo, min(hi, n))
         B, Hp, Wp, _ = x.shape
         desc = conv.plan(B, Hp - 2, Wp - 2)[3]
-        blocks = ops.conv_wgrad_blocks(desc, 256 - n)
-        if not 0 < blocks <= 256 - n:      # not the one-block-per-CU kernel (small problems): the model's n
-            return desc, 256 - n, n
-        # The weight gradient's pixel split is a whole number of blocks per (cout, cin) tile (205 blocks for a budget
-        # of 208; 160 for 232 with 80 tiles), and blocks go to the 8 XCDs round-robin by block index, per kernel: it
-        # puts ceil(blocks / 8) on each XCD, so the pass may take 32 minus that on EACH.  One block more on any XCD
-        # waits for a weight-gradient block to finish there -- the pass then takes as long as the weight gradient plus
-        # itself (measured: 19.1 -> 27 ms per step whenever the dispatch order fell that way).
-        return desc, 256 - n, 8 * (32 - (blocks + 7) // 8)
+        budget, n = ops.plan_cu_share(desc, elements, tensors, gbps, us0 if us is None else us, lo, hi)
+        return desc, budget, n
 
     def _share_pair(self, conv, x, gout, elements, tensors, us=None):
         """Issue conv's weight gradient on the second stream next to the pass that follows; returns the pass's CUs."""

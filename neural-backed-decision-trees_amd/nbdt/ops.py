@@ -266,6 +266,22 @@ def conv_wgrad_blocks(desc, cu_budget=0):
     return int(lib().nbdt_conv_wgrad_blocks(ctypes.byref(desc)))
 
 
+def plan_cu_share(desc, elements, tensors, gbps_per_cu, target_us, min_cus, max_cus):
+    """(CU budget of the weight gradient of `desc`, CUs of the HBM-bound pass of `tensors` tensors of `elements` bf16
+    that runs beside it).  n = bytes / (gbps_per_cu x target_us), clamped; then the XCD rule: thread blocks go to the
+    8 XCDs round-robin by block index, per kernel -- the weight gradient's blocks (a whole number of pixel splits per
+    (cout, cin) tile: 205 for a budget of 208, 160 for 232 with 80 tiles) put ceil(blocks / 8) on each XCD, so the
+    pass may take 32 minus that on EACH.  One block more on any XCD waits for a weight-gradient block to finish there
+    and the pass takes as long as both (measured: 19.1 -> 27 ms per step whenever the dispatch order fell that way).
+    Host arithmetic only."""
+    n = int(round(elements * 2 * tensors / (gbps_per_cu * 1e9 * target_us * 1e-6)))
+    n = max(int(min_cus), min(int(max_cus), n))
+    blocks = conv_wgrad_blocks(desc, 256 - n)
+    if not 0 < blocks <= 256 - n:      # not the one-block-per-CU kernel (small problems): the model's n
+        return 256 - n, n
+    return 256 - n, 8 * (32 - (blocks + 7) // 8)
+
+
 def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):
     check(lib().nbdt_weight_prep(ptr(w_fp32), cout, taps, cin, ptr(w_bf16), ptr(wd_bf16),
                                  stream_ptr(w_fp32.device)))

@@ -63,6 +63,32 @@ def test_weight_gradient_block_count_query_is_host_only():
     assert ops.conv_wgrad_blocks(ops.conv_wgrad_desc(512, 32, 32, 160, 320, 1, 1), 208) == 0  # 1x1
 
 
+def test_cu_share_plan_respects_the_xcd_rule():
+    """ops.plan_cu_share (engine.set_cu_share's arithmetic): the CUs of the confined BatchNorm pass plus the weight
+    gradient's blocks never exceed 32 per XCD, for the shapes and settings bench.py runs (fused sums: 3 / 4 tensor
+    passes at 200 us; split form: 5 / 6 at 190 us) and over a sweep."""
+    from nbdt import ops
+    shapes = [(512, 32, 32, 160), (512, 16, 16, 320), (512, 8, 8, 640), (256, 32, 32, 160), (1024, 16, 16, 320)]
+    seen = {}
+    for (B, H, W, C) in shapes:
+        d = ops.conv_wgrad_desc(B, H, W, C, C, 3, 1)
+        for tensors, us, hi in [(3, 200.0, 96), (4, 200.0, 96), (5, 190.0, 128), (6, 190.0, 128)]:
+            budget, n = ops.plan_cu_share(d, B * H * W * C, tensors, 47.0, us, 16, hi)
+            blocks = ops.conv_wgrad_blocks(d, budget)
+            assert 0 < blocks <= budget and n % 8 == 0 and n >= 8
+            assert (blocks + 7) // 8 + n // 8 <= 32, (B, H, W, C, tensors, budget, blocks, n)
+            seen[(B, C, tensors)] = (budget, blocks, n)
+        for us in range(100, 400, 37):
+            for tensors in (3, 4, 5, 6):
+                budget, n = ops.plan_cu_share(d, B * H * W * C, tensors, 47.0, float(us), 16, 160)
+                blocks = ops.conv_wgrad_blocks(d, budget)
+                assert (blocks + 7) // 8 + n // 8 <= 32
+    # what the benched configuration runs (DESIGN.md section 5)
+    assert seen[(512, 160, 3)] == (202, 200, 56) and seen[(512, 160, 4)] == (185, 185, 64)
+    assert seen[(512, 160, 5)] == (162, 160, 96) and seen[(512, 160, 6)] == (143, 140, 112)
+    assert seen[(512, 320, 5)][1:] == (200, 56) and seen[(512, 640, 5)][1:] == (160, 96)
+
+
 def test_product_path_refuses_cpu_tensors():
     from nbdt.loss import SoftTreeSupLoss
     from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules

@@ -44,13 +44,15 @@ PEAK_BF16_TFLOPS = 2500.0
 GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
 
 
-TRAFFIC_FILES = ("r02_final_hbm_traffic.json", "r01_final_hbm_traffic.json")   # newest first
+TRAFFIC_FILES = ("r03_split_hbm_traffic.json", "r02_final_hbm_traffic.json")   # newest first
 
 
 def pmc_traffic():
-    """(bytes, source file): HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same command;
-    scratch/prof_bench.sh).  bench.py cannot collect PMC counters itself -> (None, None) if absent."""
+    """(bytes, source file): HBM-side bytes per launch of the dominant kernel family -- launch-weighted over the
+    forward / data-gradient kernels of the schedule this file times (plain-epilogue data gradients) -- from the
+    committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same
+    command with --no-overlap; scratch/r03_run1.sh).  bench.py cannot collect PMC counters itself -> (None, None)
+    if absent."""
     for fname in TRAFFIC_FILES:
         path = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(path):
@@ -157,8 +159,15 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="every launch on one stream (profiling passes: a kernel's duration is then its own)")
     ap.add_argument("--no-cu-share", action="store_true",
-                    help="default schedule: weight gradients beside the data gradients, BatchNorm-backward passes on "
-                         "all CUs (engine.set_cu_share(None)); A/B of the CU-sharing schedule")
+                    help="weight gradients beside the data gradients, BatchNorm-backward passes on all CUs "
+                         "(engine.set_cu_share(None)); A/B of the CU-sharing schedule the engine runs by default")
+    ap.add_argument("--cu-share-force", action="store_true",
+                    help="CU sharing without the calibration (counter-collection passes serialise the kernels, so a "
+                         "calibration under rocprofv3 --pmc would turn the schedule off)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (default: nccl = RCCL).  gloo accepts device "
+                         "tensors, so `--gpus 2 --backend gloo --share-gpu` runs the N-rank branch on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (tests on a 1-GPU box)")
     ap.add_argument("--agreement-n", type=int, default=512, help="images in the prediction-agreement check (0: skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -169,10 +178,12 @@ def main():
     from nbdt import ops
     from nbdt.loss import SoftTreeSupLoss
 
-    rank, world, local = ndist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = ndist.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     comm = ndist.GradComm() if world > 1 else None
@@ -182,9 +193,13 @@ def main():
                            hierarchy="induced-wrn28_10_cifar10")
     if args.no_overlap:
         eng.set_overlap(False)
-    # BatchNorm-backward passes on ~50 CUs beside the weight gradients on the other ~200 (engine.set_cu_share): the
-    # first backward of the warm-up times one pair both ways and keeps the schedule only if it is faster on this box
-    eng.set_cu_share(None if args.no_cu_share else 47.0)
+    # BatchNorm-backward passes on ~100 CUs beside the weight gradients on the other ~160 is the engine's default
+    # (engine.set_cu_share): before the first backward of the warm-up the engine times one conv's backward in both
+    # orders and keeps the schedule only if it is faster on this box; with N ranks, rank 0 decides for all
+    if args.no_cu_share:
+        eng.set_cu_share(None)
+    elif args.cu_share_force:
+        eng.set_cu_share(47.0, calibrate=False)
     g = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
     y = torch.randint(0, args.classes, (args.batch,), generator=g).to(dev)
@@ -223,6 +238,17 @@ def main():
         ops.set_timer(None)
         eng.set_overlap(not args.no_overlap)
 
+    # The weight gradients as they run IN the timed step: on the second stream, sized for the CUs the confined
+    # BatchNorm passes leave them.  Events are recorded on the stream the launch goes to (ops.conv_wgrad).
+    in_step = None
+    if timer is not None and not args.no_overlap:
+        in_step = ops.KernelTimer(only=("conv_wgrad",))
+        ops.set_timer(in_step)
+        for _ in range(roof_steps):
+            E.train_step(eng, crit, img, y, lr, comm=comm)
+        sync()
+        ops.set_timer(None)
+
     dt_nocomm = None
     if world > 1:
         # what the gradient exchange costs a step: the same loop without it (ranks drift apart, nothing after
@@ -237,6 +263,8 @@ def main():
         t = torch.tensor([dt, dt_nocomm], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, dt_nocomm = t.tolist()
+        shares = [None] * world          # every rank's schedule (rank 0's calibration decides for all)
+        torch.distributed.all_gather_object(shares, bool(eng._cu_share is not None))
     if rank != 0:
         return
 
@@ -257,6 +285,7 @@ def main():
         out["cu_share"] = eng.cu_share_report
     if world > 1:
         out["comm"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                       "cu_share_per_rank": shares,
                        "allreduce_bytes_per_rank": int(eng.store.grad.numel()) * 4, "buckets": 3,
                        "ms_per_step_without_allreduce": round(1e3 * dt_nocomm, 3),
                        "allreduce_ms_exposed": round(ms - 1e3 * dt_nocomm, 3)}
@@ -279,11 +308,23 @@ def main():
                                                 "stream joined (no concurrent kernel)"}
         w = summ.get("conv_wgrad")
         if w:
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv_wgrad_kernel", "achieved": round(w["tflops"], 1),
+            out["roofline_wgrad"] = {"bound": "mfma",
+                                     "kernel": "conv_wgrad: conv_wgrad_pp_kernel (22 of 27 launches) / "
+                                               "conv_wgrad_dma_kernel (strided, 1x1, 16-channel input)",
+                                     "achieved": round(w["tflops"], 1),
                                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(w["tflops"] / PEAK_BF16_TFLOPS, 4),
                                      "avg_launch_us": round(w["avg_us"], 1),
-                                     "launches_per_step": w["launches"] // roof_steps}
+                                     "launches_per_step": w["launches"] // roof_steps,
+                                     "measured": "alone: one stream, all 256 CUs (cu_budget 0)"}
+            wi = in_step.summary().get("conv_wgrad") if in_step is not None else None
+            if wi:   # the launch the timed step makes: second stream, CU-budgeted, a confined BatchNorm pass beside it
+                out["roofline_wgrad"].update({
+                    "in_step_us": round(wi["avg_us"], 1), "in_step_achieved": round(wi["tflops"], 1),
+                    "in_step_frac": round(wi["tflops"] / PEAK_BF16_TFLOPS, 4),
+                    "in_step_measured": "HIP events on the second stream around every weight-gradient launch of "
+                                        f"{roof_steps} further steps of the timed schedule (CU-budgeted launches beside "
+                                        "the CU-confined BatchNorm passes; fraction of the FULL chip's peak)"})
             out["step_ms_in_mfma_kernels"] = round((k["ms"] + w["ms"]) / roof_steps, 3) if k else None
     if world == 1 and args.agreement_n > 0:
         out["agreement"] = agreement(eng, args.classes, args.agreement_n, dev)

@@ -662,13 +662,13 @@ extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float*
   const int c8 = C / 8;
   const int py = 1024 / c8;                       // C <= 2048 (check_shape): at least 4 pixel rows
   constexpr int kForceLds = 96 * 1024;            // more than half a CU's LDS: one block per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    attr_set = true;
+  static DeviceAttr site;
+  if (site.need(kForceLds)) {
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    site.done(kForceLds);
   }
   int blocks = cus;
   const int max_blocks = (g.npix + py - 1) / py;
@@ -698,11 +698,11 @@ extern "C" int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float
   const int c8 = C / 8;
   const int py = 1024 / c8;
   constexpr int kForceLds = 96 * 1024;            // one block per CU; the block fold uses py*c8*64 <= 64 KB of it
-  static bool attr_set = false;
-  if (!attr_set) {
-    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    attr_set = true;
+  static DeviceAttr site;
+  if (site.need(kForceLds)) {
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    site.done(kForceLds);
   }
   int blocks = cus;
   const int max_blocks = (g.npix + py - 1) / py;

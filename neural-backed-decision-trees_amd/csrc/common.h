@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/nbdt_hip.h"
 
 namespace nbdt {
@@ -30,6 +32,34 @@ inline int fail(int code, const char* fmt, const char* a = "", const char* b = "
   } while (0)
 
 #define NBDT_LAUNCH_CHECK() NBDT_HIP_CHECK(hipGetLastError())
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel, so "the attribute is set" is a per-device
+// fact.  One DeviceAttr per launch site: need(bytes) returns true (holding the site's mutex until done()) when the
+// current device has not been configured for at least `bytes` of dynamic LDS yet.  Thread-safe; ~20 ns per launch
+// once configured.
+struct DeviceAttr {
+  static constexpr int kMaxDevices = 64;
+  std::mutex m;
+  size_t bytes[kMaxDevices] = {};
+  int dev = 0;
+  bool need(size_t want) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if (d < 0 || d >= kMaxDevices) d = kMaxDevices - 1;
+    m.lock();
+    dev = d;                     // (owned by whoever holds the mutex)
+    if (bytes[d] >= want && want > 0) { m.unlock(); return false; }
+    return true;                 // caller sets the attributes, then calls done(want)
+  }
+  void done(size_t want) { bytes[dev] = want ? want : 1; m.unlock(); }
+  void abort() { m.unlock(); }
+};
+// NBDT_HIP_CHECK for use between need() and done(): releases the site's mutex on failure
+#define NBDT_ATTR_CHECK(site, expr)                                                       \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) { (site).abort(); return nbdt::fail(NBDT_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); } \
+  } while (0)
 
 typedef unsigned short bf16_t;  // raw bf16 bits
 

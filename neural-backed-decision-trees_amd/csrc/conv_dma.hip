@@ -176,15 +176,15 @@ static int launch_dma(ConvDmaParams& p, hipStream_t st) {
   const int items = p.m_blocks * p.n_blocks;
   p.per_xcd = (items + 7) / 8;
   const size_t shmem = (size_t)NSTAGE * ((BM * BK * 2) + (BN * BK * 2));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceAttr site;     // one per NT instantiation
+  if (site.need(shmem)) {
 #define NBDT_ATTR(R, S)                                                                                         \
-  NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<NT, R, S>),           \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+  NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<NT, R, S>),    \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
     NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
     NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
 #undef NBDT_ATTR
-    attr_set = true;
+    site.done(shmem);
   }
   const dim3 grid(p.per_xcd * 8), blk(256);
 #define NBDT_GO(R, S) hipLaunchKernelGGL((conv_igemm_dma_kernel<NT, R, S>), grid, blk, shmem, st, p)

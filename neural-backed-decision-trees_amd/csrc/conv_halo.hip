@@ -685,18 +685,18 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
     p.overlap = 0;
 #endif
   }
-  static size_t attr_bytes = 0;
+  static DeviceAttr site;     // one per (NT, KIND) instantiation; re-raised when a launch needs more LDS
   const dim3 grid(per_round * 8), blk(64 * NWV);
 #define NBDT_KERNEL(R, S) \
   (KIND == 2 ? reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>) \
              : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV>))
-  if (shmem > attr_bytes) {
+  if (site.need(shmem)) {
 #define NBDT_ATTR(R, S) \
-  NBDT_HIP_CHECK(hipFuncSetAttribute(NBDT_KERNEL(R, S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+  NBDT_ATTR_CHECK(site, hipFuncSetAttribute(NBDT_KERNEL(R, S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
     NBDT_ATTR(true, 1); NBDT_ATTR(true, 0); NBDT_ATTR(false, 1); NBDT_ATTR(false, 0); NBDT_ATTR(false, 2);
     NBDT_ATTR(true, 3); NBDT_ATTR(false, 3);
 #undef NBDT_ATTR
-    attr_bytes = shmem;
+    site.done(shmem);
   }
   void* args[] = {(void*)&p, (void*)&hg};
 #define NBDT_GO(R, S) NBDT_HIP_CHECK(hipLaunchKernel(NBDT_KERNEL(R, S), grid, blk, args, shmem, st))

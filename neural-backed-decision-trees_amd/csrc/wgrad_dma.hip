@@ -269,11 +269,11 @@ static int launch_dma(WgradDmaParams& p, hipStream_t st) {
   p.items = tiles * splits;
   p.per_xcd = (p.items + 7) / 8;
   const size_t shmem = (size_t)NSTAGE * (32 * WM / 8 + 32 * WN / 8) * 512;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NBDT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
+  static DeviceAttr site;     // one per (WM, WN) instantiation
+  if (site.need(shmem)) {
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<WM, WN>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    site.done(shmem);
   }
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<WM, WN>), dim3(p.per_xcd * 8), dim3(256), shmem, st, p);
   NBDT_LAUNCH_CHECK();

@@ -670,10 +670,10 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   const size_t shmem = PP ? (size_t)5 * (64 * 64 * WM + 144 * 64) : (size_t)NSTAGE * ((32 * WM / 8) * 512 + x_bytes(4));
   const void* fn = PP ? reinterpret_cast<const void*>(&conv_wgrad_pp_kernel<WM>)
                       : reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, 4>);
-  static bool attr_set = false;
-  if (!attr_set) {
-    NBDT_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
+  static DeviceAttr site;     // one per (WM, PP) instantiation
+  if (site.need(shmem)) {
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    site.done(shmem);
   }
   void* args[] = {(void*)&p};
   NBDT_HIP_CHECK(hipLaunchKernel(fn, dim3(p.per_xcd * 8), dim3(PP ? 512 : 256), args, shmem, st));

@@ -73,6 +73,14 @@ class GradComm:
         else:
             self._work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def broadcast_flag(self, flag, device):
+        """Rank 0's boolean, adopted by every rank (schedule decisions that must not differ between replicas)."""
+        if self.world_size == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return bool(t.item())
+
     def finish(self, flat=None):
         """Order every outstanding all-reduce before subsequent work on the current stream."""
         for w in self._work:

@@ -254,6 +254,7 @@ class _Engine:
         self.convs, self.bns = [], []
         self.training = True
         self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
+        self.debug_share_serial = False   # tests: the CU-sharing schedule's exact launches (CU counts, budgets) on ONE stream
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
@@ -304,6 +305,8 @@ class _Engine:
                      split_reduce=True, split_target_us=190.0):
         """Run the BatchNorm-backward pass of every fused WRN unit BESIDE the weight gradient of the same conv, on
         disjoint CUs (gbps_per_cu=None: off -- weight gradients next to the data gradients, every pass on all CUs).
+        WRNEngine turns this on at construction (calibrated, see below), so main.py / HipBackbone users and bench.py
+        run the same schedule.
 
         Why it pays (probes/cu_share_probe.hip, profiles/r02_cu_share_probe.txt): the pass is HBM-bound and HBM needs
         few CUs -- one CU streams ~47 GB/s, 64 CUs 3.0 TB/s, all 256 5.6 TB/s -- while the MFMA-bound weight gradient
@@ -312,25 +315,34 @@ class _Engine:
         can never share a CU (a weight-gradient block takes its whole register file), so the split is by CU: the pass
         runs as n persistent one-per-CU blocks (nbdt_bn_bwd_apply_cus), the weight gradient is sized for the rest
         (nbdt_wgrad_desc.cu_budget).  n = bytes of the pass / (gbps_per_cu x target_us), clamped to
-        [min_cus, max_cus] and then set by the weight gradient's actual block count per XCD (_share_plan).
+        [min_cus, max_cus] and then set by the weight gradient's actual block count per XCD (ops.plan_cu_share).
         split_reduce: the BatchNorm-backward SUMS move there too -- the data gradients run with their plain epilogue
         (the fused one reads the BatchNorm input in an HBM burst while the matrix pipes wait: 240 instead of 190 us
         per stage-1 launch) and the confined work becomes reduce + fold + apply (nbdt_bn_bwd_reduce_cus +
         nbdt_bn_bwd_apply_cus: 5-6 tensor passes instead of 3-4, so n is larger: split_target_us).  Same-box A/B at
-        512 images: 19.30 ms per step without sharing, 18.37 with the fused sums, 17.73 with the split.
+        512 images: 19.25 ms per step without sharing, 18.45 with the fused sums, 17.55 with the split
+        (profiles/r03_split_cu_share_ab.txt).
         join: wait for the weight gradient before the next data gradient (bounds the cost of an unbalanced pair to
         max(pass, weight gradient); measured 1 % slower when the pairs are balanced, so off by default).
-        calibrate: the first backward() times one stage-1 pair both ways on its own tensors (about a millisecond, once)
-        and turns the sharing off if the pair is not faster -- e.g. when the two streams were mapped to one hardware
-        queue and cannot overlap at all, where a pass confined to 50 CUs would cost 35 % of a step.
+        calibrate: calibrate_cu_share() runs before the first backward() at a new setting (or when the caller invokes
+        it): it times the conv2 half of one stage-1 unit in the default order and in the order that would be used, on
+        the engine's own buffers, and keeps the sharing only if it is faster -- e.g. not when the two streams were
+        mapped to one hardware queue and cannot overlap at all, where a pass confined to 50 CUs costs 35 % of a step.
         Only the second stream the engine was created with is used: streams created later wrapped onto the main
-        stream's hardware queue in one of four tries (measured), never the first one."""
+        stream's hardware queue in one of four tries (measured), never the first one.
+        The CU arithmetic is MI355X's (256 CUs = 8 XCDs x 32): on any other device the sharing stays off."""
         self.join_side_stream()
-        self._cu_share = None if gbps_per_cu is None else (float(gbps_per_cu), float(target_us), int(min_cus), int(max_cus))
+        self.cu_share_report = None
         self._share_join = bool(join)
         self._share_split = bool(split_reduce), float(split_target_us)
+        if gbps_per_cu is not None and not ops.cu_topology_is_mi355x(self.device):
+            self._cu_share = None
+            self._share_calibrated = True
+            self.cu_share_report = {"enabled": False, "reason": "not a 256-CU / 8-XCD device: the CU split is MI355X's"}
+            return
+        self._cu_share = None if gbps_per_cu is None else (float(gbps_per_cu), float(target_us),
+                                                           max(8, int(min_cus)), int(max_cus))
         self._share_calibrated = not calibrate
-        self.cu_share_report = None
 
     def _share_plan(self, conv, x, elements, tensors, us=None):
         """(weight-gradient descriptor, its CU budget, CUs for the elementwise pass of `tensors` tensors of `elements`
@@ -347,29 +359,76 @@ class _Engine:
         conv.backward_weight(x, gout, cu_budget=budget)
         return n
 
-    def _calibrate_share(self, conv, x, gout, bn, gy, bx, gx, partials, elements, tensors):
-        """Time one (weight gradient, BatchNorm-backward pass) pair on its real operands: back to back on all CUs,
-        and side by side on disjoint CUs.  Every output goes to scratch (gx is rewritten by the real pass that
-        follows).  Turns the sharing off unless the pair is at least 5 % faster side by side."""
+    def _calibration_unit(self):
+        """The unit whose conv2 pair the calibration times (subclasses with CU sharing override)."""
+        return None
+
+    def calibrate_cu_share(self, comm=None):
+        """Decide whether the CU-sharing schedule set by set_cu_share() is kept on THIS box: time the conv2 half of one
+        widest-tensor unit -- data gradient, BatchNorm backward, weight gradient, exactly the launches backward()
+        would make -- in the default order and in the sharing order that is configured (split or fused sums), each
+        4 times on the engine's own buffers (about 3 ms, once), and keep the sharing only if it is at least 3 %
+        faster.  Needs a training-mode forward() at the batch size that will be trained (it uses that forward's
+        activations and BatchNorm statistics); backward() calls it before its first launch when a new setting has not
+        been calibrated yet.  It synchronises with the host, so it must not run inside a hipGraph capture (GraphedStep
+        warms up, and thereby calibrates, before it captures).
+        comm (a GradComm of more than one rank): every rank measures, rank 0's decision is broadcast and adopted by
+        all, so the ranks of a data-parallel job never run different schedules (the slowest would set the pace)."""
         self._share_calibrated = True
-        desc, budget, n = self._share_plan(conv, x, elements, tensors)
+        if self._cu_share is None:
+            return self.cu_share_report
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("calibrate_cu_share() synchronises with the host: call it (or run one eager step) "
+                               "before capturing the step in a hipGraph")
+        u = self._calibration_unit()
+        if u is None or self._side is None or getattr(self, "_B", None) is None:
+            self._cu_share = None
+            self.cu_share_report = {"enabled": False, "reason": "no unit / second stream / forward to calibrate on"}
+            return self.cu_share_report
+        B = self._B
+        k, cout = u["key"], _pad32(u["cout"])
+        x_out = u["x_out"]
+        h, w = x_out.shape[1] - 2, x_out.shape[2] - 2
+        conv, bn = u["conv2"], u["bn2"]
+        a2, t = self.buf(k + ".a2", B, h, w, cout), self.buf(k + ".t", B, h, w, cout)
+        ga2, gt = self.buf(f"ga2_{cout}", B, h, w, cout), self.buf(f"gt_{cout}", B, h, w, cout)
+        g = self.buf(f"g_in{cout}_{h}_0", B, h, w, cout)      # backward() rewrites all three before it reads them
+        ops.interior(g).normal_(0.0, 1e-3)                    # (plumbing: a one-off fill so the MFMAs see real data)
+        split, split_us = self._share_split
+        elements = B * h * w * cout
+        desc, budget, n = self._share_plan(conv, a2, elements, 5 if split else 3, split_us if split else None)
         main = torch.cuda.current_stream(self.device)
         dw = torch.zeros_like(self.store.g(conv.name))
         dsum = torch.empty(2 * bn.C, device=self.device)
         dg, db = torch.zeros(bn.C, device=self.device), torch.zeros(bn.C, device=self.device)
+        partials, scratch = self.partials(t), self.scratch(bn.C)
+        plan = conv.plan(B, h, w)
+        d_plain = plan[1][0]
 
-        def bn_pass(cus):
-            ops.bn_bwd_fused(gy, bx, bn.mean, bn.rstd, bn.gamma, bn.beta, partials, dsum, dg, db, gx, cus=cus)
+        def dgrad(fused):
+            if fused:
+                ops.conv_igemm_bnbwd(d_plain, g, conv.wd, ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta, partials)
+            else:
+                ops.conv_igemm(d_plain, g, conv.wd, ga2)
 
-        def serial():
-            ops.conv_wgrad(desc, x, gout, dw, 0)
-            bn_pass(0)
-
-        def paired():
+        def wgrad_side(cu_budget):
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                ops.conv_wgrad(desc, x, gout, dw, budget)
-            bn_pass(n)
+                ops.conv_wgrad(desc, a2, g, dw, cu_budget)
+
+        def default_order():        # what backward() does with set_cu_share(None)
+            wgrad_side(0)
+            dgrad(True)
+            ops.bn_bwd_fused(ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta, partials, dsum, dg, db, gt)
+            main.wait_stream(self._side)
+
+        def sharing_order():
+            dgrad(not split)
+            wgrad_side(budget)
+            if split:
+                ops.bn_bwd_cus(ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta, scratch, dsum, dg, db, gt, n)
+            else:
+                ops.bn_bwd_fused(ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta, partials, dsum, dg, db, gt, cus=n)
             main.wait_stream(self._side)
 
         def best_us(fn):
@@ -383,14 +442,21 @@ class _Engine:
                 best = min(best, e0.elapsed_time(e1) * 1e3)
             return best
 
-        t_serial, t_pair = best_us(serial), best_us(paired)
-        keep = t_pair < 0.95 * t_serial
-        self.cu_share_report = {"pass_cus": n, "wgrad_cu_budget": budget, "serial_us": round(t_serial, 1),
-                                "side_by_side_us": round(t_pair, 1), "enabled": bool(keep),
-                                "bn_sums": "beside the weight gradient (nbdt_bn_bwd_reduce_cus)" if self._share_split[0]
+        t_default, t_share = best_us(default_order), best_us(sharing_order)
+        keep = t_share < 0.97 * t_default
+        decided_by = "this rank"
+        if comm is not None and comm.world_size > 1:
+            keep = comm.broadcast_flag(keep, self.device)
+            decided_by = "rank 0 (broadcast)"
+        self.cu_share_report = {"pass_cus": n, "wgrad_cu_budget": budget, "default_order_us": round(t_default, 1),
+                                "sharing_order_us": round(t_share, 1), "enabled": bool(keep), "decided_by": decided_by,
+                                "timed": f"conv2 half of unit {k} (data gradient + BatchNorm backward + weight "
+                                         f"gradient) at batch {B}",
+                                "bn_sums": "beside the weight gradient (nbdt_bn_bwd_reduce_cus)" if split
                                            else "data-gradient epilogue"}
         if not keep:
             self._cu_share = None
+        return self.cu_share_report
 
     def join_side_stream(self):
         """Order every weight-gradient launch issued on the side stream before what follows on the main one."""
@@ -574,6 +640,15 @@ class WRNEngine(_Engine):
         self._side = torch.cuda.Stream(device=self.device)     # engine.set_overlap(False) puts everything back
         for c in self.convs:                                   # on the caller's stream (profiling passes)
             c.side_stream = self._side
+        # BatchNorm-backward passes beside the weight gradients on disjoint CUs: on by default, kept only if the
+        # calibration before the first backward() finds it faster on this box (set_cu_share(None) turns it off)
+        self.set_cu_share(47.0)
+
+    def _calibration_unit(self):
+        for u in self.units:      # a widest-tensor unit without a shape change: both of its convs are dense 3x3
+            if u["idconv"] is None and u["cout"] == self.units[0]["cout"]:
+                return u
+        return None
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, img, training=None):
@@ -635,6 +710,9 @@ class WRNEngine(_Engine):
         With a GradComm, each stage's gradient bucket is all-reduced as soon as it is complete."""
         B = self._B
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
+        if self._cu_share is not None and not self._share_calibrated:
+            self.calibrate_cu_share(comm)      # once per set_cu_share(): keep the sharing only if it is faster here
+        two_streams = self._side is not None and self._overlap
         buckets = self.grad_buckets() if comm is not None else None
         gz = gz.contiguous()
         st = self.store
@@ -669,39 +747,28 @@ class WRNEngine(_Engine):
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             fuse = self.fuse_stats
-            if (self._cu_share is not None and self._share_split[0]
-                    and not (self._side is not None and self._overlap)):
-                # one-stream mode (profiling passes, bench.py's roofline pass) of the split schedule: the same kernels
-                # as the timed step -- data gradients with their plain epilogue, BatchNorm sums in a pass of their
-                # own -- back to back on all CUs
-                fuse = False
             # CU sharing (set_cu_share): each weight gradient is issued AFTER the data gradient of its conv and sized
             # for 256 - n CUs, and the BatchNorm-backward pass that follows on this stream is confined to n CUs, so
-            # the HBM-bound pass and the MFMA-bound kernel run at the same time on disjoint CUs.
-            share = self._cu_share is not None and fuse and self._side is not None and self._overlap
-            if share and not self._share_calibrated:
-                # the very first backward keeps the default order until it reaches a widest-tensor (stage-1) unit,
-                # calibrates the sharing on that unit's conv2 pair, and goes on with what the measurement says
-                share = u["idconv"] is None and u["cout"] == self.units[0]["cout"]
-            if not share:
-                u["conv2"].backward_weight(a2, g)
-            split = share and self._share_calibrated and self._share_split[0]
+            # the HBM-bound pass and the MFMA-bound kernel run at the same time on disjoint CUs.  In its split form
+            # the BatchNorm-backward sums move out of the data gradient's epilogue (which reads the BatchNorm input in
+            # an HBM burst while the matrix pipes wait) into the CU-confined pass beside the weight gradient.
+            share = self._cu_share is not None and fuse and (two_streams or self.debug_share_serial)
+            split = share and self._share_split[0]
+            if self._cu_share is not None and self._share_split[0] and fuse and not share:
+                # one-stream mode (profiling passes, bench.py's roofline pass) of the split schedule: the same MFMA
+                # kernels as the timed step -- data gradients with their plain epilogue -- and the BatchNorm sums in a
+                # pass of their own, back to back on all CUs
+                fuse = False
             if split:
-                # the BatchNorm-backward sums move out of the data gradient's epilogue (which reads the BatchNorm input
-                # in an HBM burst while the matrix pipes wait) into the CU-confined pass beside the weight gradient
                 u["conv2"].backward_data(g, ga2)
                 n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 5, self._share_split[1])
                 u["bn2"].backward_cus(ga2, t, gt, n2)
                 if self._share_join:
                     self.join_side_stream()
             elif fuse:   # the dgrad epilogue also produces bn2's backward sums (ga2 is not re-read for them)
+                if not share:
+                    u["conv2"].backward_weight(a2, g)
                 u["conv2"].backward_data(g, ga2, bn=u["bn2"], bn_x=t, partials=self.partials(t))
-                if share and not self._share_calibrated:
-                    self._calibrate_share(u["conv2"], a2, g, u["bn2"], ga2, t, gt, self.partials(t),
-                                          B * ho * wo * cout, 3)
-                    share = self._cu_share is not None
-                    if not share:       # the weight gradient the default order would have issued before the dgrad
-                        u["conv2"].backward_weight(a2, g)
                 n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 3) if share else 0
                 u["bn2"].backward_fused(ga2, t, gt, self.partials(t), cus=n2)
                 if share and self._share_join:
@@ -712,6 +779,7 @@ class WRNEngine(_Engine):
                     # here makes an unbalanced pair cost max(pass, weight gradient), never more.
                     self.join_side_stream()
             else:
+                u["conv2"].backward_weight(a2, g)
                 u["conv2"].backward_data(g, ga2)
                 u["bn2"].backward(ga2, None, t, gt, relu=True)   # mask recomputed from t: a2 not re-read
             if split and u["idconv"] is None:

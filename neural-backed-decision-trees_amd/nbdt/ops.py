@@ -150,8 +150,12 @@ class KernelTimer:
     """Brackets every conv_igemm / conv_wgrad launch with HIP events on the stream the kernel is
     launched on (torch's current stream) and accumulates algorithmic flops per kernel family."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.items = []   # (kind, flops, start_event, end_event)
+        self.only = only  # restrict to these kinds (None: all)
+
+    def wants(self, kind):
+        return self.only is None or kind in self.only
 
     def bracket(self, kind, flops, device):
         s = torch.cuda.Event(enable_timing=True)
@@ -187,7 +191,7 @@ def set_timer(t):
 def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
     """bn_scratch: also accumulate the output's per-channel sum / sum-of-squares for the next BatchNorm."""
     ev = None
-    if _timer is not None:
+    if _timer is not None and _timer.wants("conv_igemm"):
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
         ev = _timer.bracket("conv_igemm", flops, inp.device)
         ev[0].record()
@@ -204,7 +208,7 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
 def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, partials):
     """dgrad launch that also produces the BatchNorm-backward sums of (out, bn_x) as per-tile partials."""
     ev = None
-    if _timer is not None:
+    if _timer is not None and _timer.wants("conv_igemm"):
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
         ev = _timer.bracket("conv_igemm", flops, inp.device)
         ev[0].record()
@@ -250,7 +254,7 @@ def conv_wgrad(desc, x, gy, dw, cu_budget=0):
     """cu_budget: size the launch for that many CUs (0 = all) -- see nbdt_wgrad_desc.cu_budget."""
     desc.cu_budget = int(cu_budget)
     ev = None
-    if _timer is not None:
+    if _timer is not None and _timer.wants("conv_wgrad"):
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
         ev = _timer.bracket("conv_wgrad", flops, x.device)
         ev[0].record()
@@ -266,20 +270,37 @@ def conv_wgrad_blocks(desc, cu_budget=0):
     return int(lib().nbdt_conv_wgrad_blocks(ctypes.byref(desc)))
 
 
+MI355X_CUS, MI355X_XCDS = 256, 8
+
+
+def cu_topology_is_mi355x(device):
+    """The CU-sharing arithmetic below is MI355X's: 256 CUs in 8 XCDs of 32, thread blocks dealt to the XCDs
+    round-robin.  Anything else (MI300X: 304 CUs, 38 per XCD) gets no sharing rather than a wrong split."""
+    props = torch.cuda.get_device_properties(device)
+    return props.multi_processor_count == MI355X_CUS and "gfx950" in getattr(props, "gcnArchName", "gfx950")
+
+
 def plan_cu_share(desc, elements, tensors, gbps_per_cu, target_us, min_cus, max_cus):
     """(CU budget of the weight gradient of `desc`, CUs of the HBM-bound pass of `tensors` tensors of `elements` bf16
-    that runs beside it).  n = bytes / (gbps_per_cu x target_us), clamped; then the XCD rule: thread blocks go to the
-    8 XCDs round-robin by block index, per kernel -- the weight gradient's blocks (a whole number of pixel splits per
-    (cout, cin) tile: 205 for a budget of 208, 160 for 232 with 80 tiles) put ceil(blocks / 8) on each XCD, so the
-    pass may take 32 minus that on EACH.  One block more on any XCD waits for a weight-gradient block to finish there
-    and the pass takes as long as both (measured: 19.1 -> 27 ms per step whenever the dispatch order fell that way).
-    Host arithmetic only."""
+    that runs beside it).  n = bytes / (gbps_per_cu x target_us), clamped to [max(8, min_cus), max_cus]; then the XCD
+    rule: thread blocks go to the 8 XCDs round-robin by block index, per kernel -- the weight gradient's blocks (a
+    whole number of pixel splits per (cout, cin) tile: 205 for a budget of 208, 160 for 232 with 80 tiles) put
+    ceil(blocks / 8) on each XCD, so the pass may take 32 minus that on EACH.  One block more on any XCD waits for a
+    weight-gradient block to finish there and the pass takes as long as both (measured: 19.1 -> 27 ms per step
+    whenever the dispatch order fell that way).  A budget whose blocks would leave the pass less than one CU per XCD
+    is lowered by 8 until they do, so the pass never gets 0 CUs.  Host arithmetic only."""
+    per_xcd = MI355X_CUS // MI355X_XCDS
     n = int(round(elements * 2 * tensors / (gbps_per_cu * 1e9 * target_us * 1e-6)))
-    n = max(int(min_cus), min(int(max_cus), n))
-    blocks = conv_wgrad_blocks(desc, 256 - n)
-    if not 0 < blocks <= 256 - n:      # not the one-block-per-CU kernel (small problems): the model's n
-        return 256 - n, n
-    return 256 - n, 8 * (32 - (blocks + 7) // 8)
+    n = max(max(8, int(min_cus)), min(int(max_cus), n))
+    n = min(n, MI355X_CUS - MI355X_XCDS)
+    while True:
+        blocks = conv_wgrad_blocks(desc, MI355X_CUS - n)
+        if not 0 < blocks <= MI355X_CUS - n:      # not the one-block-per-CU kernel (small problems): the model's n
+            return MI355X_CUS - n, n
+        free = MI355X_XCDS * (per_xcd - (blocks + MI355X_XCDS - 1) // MI355X_XCDS)
+        if free >= MI355X_XCDS or n + MI355X_XCDS > MI355X_CUS - MI355X_XCDS:
+            return MI355X_CUS - n, max(free, MI355X_XCDS)
+        n += MI355X_XCDS
 
 
 def weight_prep(w_fp32, cout, taps, cin, w_bf16=None, wd_bf16=None):

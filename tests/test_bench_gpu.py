@@ -31,3 +31,28 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+
+
+def test_bench_two_rank_branch_runs_on_one_gpu_over_gloo():
+    """`bench.py --gpus 2` re-launches itself through torch.distributed.run (one rank per GPU over RCCL on a
+    multi-GPU node).  On a 1-GPU box the same branch -- self-launch, per-rank shard, GradComm buckets reduced during
+    backward, rank 0's CU-sharing decision broadcast, max-over-ranks timing, the `comm` object -- runs with both ranks
+    on cuda:0 exchanging through gloo (--backend gloo --share-gpu), so the driver's scaling run is never the first
+    execution of that code."""
+    import torch
+    multi = torch.cuda.device_count() >= 2
+    extra = [] if multi else ["--backend", "gloo", "--share-gpu"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "64", "--no-cpu-baseline", "--agreement-n", "0"] + extra,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    c = d["comm"]
+    assert c["ranks"] == 2 and c["backend"] == ("nccl" if multi else "gloo") and c["buckets"] == 3
+    assert c["allreduce_bytes_per_rank"] > 4 * 36_000_000 and "allreduce_ms_exposed" in c
+    assert len(c["cu_share_per_rank"]) == 2 and c["cu_share_per_rank"][0] == c["cu_share_per_rank"][1]
+    assert abs(d["value"] - 128 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+    assert "roofline" in d and "cpu_baseline" not in d

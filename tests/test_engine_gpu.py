@@ -254,61 +254,108 @@ def test_wrn28_10_full_size_step_runs():
     assert torch.isfinite(eng.store.flat).all()
 
 
-def test_bench_configuration_step_matches_fp32_oracle(pkg_dir):
+@pytest.fixture(scope="module")
+def bench_config_oracle(pkg_dir):
+    """One fp32 CPU pass of the benched configuration (WRN-28-10, 512 images): logits, loss, parameter gradients.
+    Shared by the schedule-parametrised test below (about half a minute of host time, ~25 GB of host RAM)."""
+    import psutil
+    if psutil.virtual_memory().available < 48 << 30:
+        pytest.skip("needs 48 GB of free host memory for the CPU oracle")
+    torch.manual_seed(0)
+    ref = TM.WRN(10, 28, 10)
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(512, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (512,), generator=g)
+    ref.train()
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}     # before the forward moves the running statistics
+    z_ref, loss_ref = _oracle_loss_backward(ref, otree, x, y)
+    grads = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    del ref
+    return {"sd": sd, "x": x, "y": y, "z": z_ref, "loss": loss_ref, "grads": grads, "otree": otree}
+
+
+@pytest.mark.parametrize("schedule", ["default", "cu-share-split"])
+def test_bench_configuration_step_matches_fp32_oracle(schedule, bench_config_oracle, monkeypatch):
     """The configuration bench.py times -- WRN-28-10, 512 CIFAR10-shaped images, SoftTreeSupLoss on the
     induced-wrn28_10_cifar10 hierarchy -- one train-mode forward + loss + backward against the fp32 CPU oracle port
-    with identical weights and inputs (about half a minute of host time).  Every dense 3x3 launch here takes the
-    8-wave ping-pong kernels with 4 / 2 / 1 tiles per persistent block, the data gradients their BatchNorm-backward
-    epilogue and the weight gradients the 8-wave kernel, exactly as in the timed step (test_bench_shape_conv_forward_dgrad_wgrad asserts the kernel names at these shapes).  Tolerances as in the small
-    tests above: bf16 storage against fp32 arithmetic; the hard decisions of each path's rules on its own logits are
-    compared on top (HIP kernel vs numpy oracle).  Measured (profiles/r02_bench_config_parity.txt): logits within
-    1.35 % of their scale, loss 4.64159 vs 4.64163, argmax agreement 0.990, hard decisions 1.000, gradient cosine
-    0.986 at the last conv falling to 0.91-0.93 at the first (ReLU-mask flips of 1-ulp bf16 differences accumulate
-    over 25 layers; two runs of the engine itself differ by as much), conv-weight gradient norms within 0.4 %, the
-    16- to 640-element BatchNorm gradients within 6-17 % by run (hence 25 % for those)."""
-    import psutil
-    from nbdt import _C
+    with identical weights and inputs, in BOTH backward schedules: `default` (set_cu_share(None): fused-sums data
+    gradients, every pass on all CUs) and `cu-share-split`, the one the engine runs by default and bench.py times
+    (plain-epilogue data gradients, nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus on 56-112 CUs beside CU-budgeted
+    weight gradients on the second stream, gradient buffers shared between units).  A launch log asserts which
+    kernels each schedule actually ran.  Tolerances: bf16 storage against fp32 arithmetic; the hard decisions of each
+    path's rules on its own logits are compared on top (HIP kernel vs numpy oracle).  Measured
+    (profiles/r02_bench_config_parity.txt, r03_bench_config_parity.txt): logits within 1.4 % of their scale, loss
+    4.64159 vs 4.64163, argmax agreement 0.990, hard decisions 1.000, gradient cosine 0.986 at the last conv falling
+    to 0.91-0.93 at the first (ReLU-mask flips of 1-ulp bf16 differences accumulate over 25 layers), conv-weight
+    gradient norms within 0.4 %, the 16- to 640-element BatchNorm gradients within 6-17 % by run (hence 25 %)."""
+    from nbdt import _C, ops
     from nbdt.tree import Tree
-    B = 512
-    if psutil.virtual_memory().available < 48 << 30:     # the fp32 autograd graph of 512 images is ~25 GB of host RAM
-        pytest.skip("needs 48 GB of free host memory for the CPU oracle")
-    ref, eng = _pair(28, 10, 10)
-    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))
+    o = bench_config_oracle
+    eng = E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=0)
+    eng.load_state_dict(o["sd"])
+    if schedule == "default":
+        eng.set_cu_share(None)
+    else:
+        eng.set_cu_share(47.0, calibrate=False)
     crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
                            hierarchy="induced-wrn28_10_cifar10")
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(B, 3, 32, 32, generator=g)
-    y = torch.randint(0, 10, (B,), generator=g)
-    ref.train()
-    z_ref, loss_ref = _oracle_loss_backward(ref, otree, x, y)
+    log = {"bn_bwd_cus": [], "igemm_bnbwd": 0, "wgrad_budgets": []}
+    real_cus, real_bnbwd, real_wgrad = ops.bn_bwd_cus, ops.conv_igemm_bnbwd, ops.conv_wgrad
 
+    def spy_cus(*a, **k):
+        log["bn_bwd_cus"].append(a[11])
+        return real_cus(*a, **k)
+
+    def spy_bnbwd(*a, **k):
+        log["igemm_bnbwd"] += 1
+        return real_bnbwd(*a, **k)
+
+    def spy_wgrad(desc, x, gy, dw, cu_budget=0):
+        log["wgrad_budgets"].append(cu_budget)
+        return real_wgrad(desc, x, gy, dw, cu_budget)
+
+    monkeypatch.setattr(ops, "bn_bwd_cus", spy_cus)
+    monkeypatch.setattr(ops, "conv_igemm_bnbwd", spy_bnbwd)
+    monkeypatch.setattr(ops, "conv_wgrad", spy_wgrad)
+    x, y, z_ref, loss_ref = o["x"], o["y"], o["z"], o["loss"]
     eng.zero_grad()
     z = eng.forward(x.to(DEV), training=True)
     loss, gz = crit.loss_and_grad(z, y.to(DEV))
     eng.backward(gz)
     torch.cuda.synchronize()
+    # ---- which kernels ran
+    if schedule == "default":
+        assert log["igemm_bnbwd"] == 21 and not log["bn_bwd_cus"] and set(log["wgrad_budgets"]) == {0}
+    else:
+        # 12 bn2 passes + 9 bn1 passes of the units without a shape change; their weight gradients CU-budgeted
+        assert log["igemm_bnbwd"] == 0 and len(log["bn_bwd_cus"]) == 21
+        assert all(n % 8 == 0 and 16 <= n <= 128 for n in log["bn_bwd_cus"]), log["bn_bwd_cus"]
+        assert {96, 112} <= set(log["bn_bwd_cus"])            # the stage-1 plans of the benched configuration
+        assert sum(b > 0 for b in log["wgrad_budgets"]) == 21
+        assert ops.last_igemm_kernel() in ("conv3x3_pp_kernel", "conv_igemm_dma_kernel")
 
     scale = z_ref.abs().max().item()
     err = (z.cpu() - z_ref).abs().max().item()
     agree = (z.cpu().argmax(1) == z_ref.argmax(1)).float().mean().item()
     tree = Tree("CIFAR10", hierarchy="induced-wrn28_10_cifar10")
     hard = _C.hard_forward(tree.device_handle(0), z.float(), want_onehot=False)[0].cpu().numpy()
-    hard_ref = O.hard_forward(otree, z_ref.numpy())
+    hard_ref = O.hard_forward(o["otree"], z_ref.numpy())
     hard_agree = float((hard == hard_ref).mean())
-    print(f"logit err {err:.4g} of scale {scale:.4g}; loss {loss.item():.5f} vs {loss_ref:.5f}; "
+    print(f"[{schedule}] logit err {err:.4g} of scale {scale:.4g}; loss {loss.item():.5f} vs {loss_ref:.5f}; "
           f"argmax agreement {agree:.4f}; hard-decision agreement {hard_agree:.4f}")
     grads = eng.named_params("grad")
     report, worst_cos, worst_ratio = [], 1.0, 0.0
-    for name, p in ref.named_parameters():
-        c = _cos(grads[name], p.grad)
-        ratio = grads[name].float().norm().item() / p.grad.norm().item()
+    for name, gref in o["grads"].items():
+        c = _cos(grads[name], gref)
+        ratio = grads[name].float().norm().item() / gref.norm().item()
         report.append(f"cos {c:.4f} norm-ratio {ratio:.4f} {name}")
         worst_cos = min(worst_cos, c)
         worst_ratio = max(worst_ratio, abs(ratio - 1))
         if name.endswith("conv.weight"):      # 36.5 M of the 36.5 M parameters: norms within 2 % (measured 0.4 %)
             assert abs(ratio - 1) < 0.02, report[-1]
     print("\n".join(report))
-    print(f"worst gradient cosine {worst_cos:.4f}, worst norm deviation {worst_ratio:.4f}")
+    print(f"[{schedule}] worst gradient cosine {worst_cos:.4f}, worst norm deviation {worst_ratio:.4f}")
     assert err < 3e-2 * scale, (err, scale)
     assert abs(loss.item() - loss_ref) < 2e-2 * abs(loss_ref)
     assert agree >= BENCH_CFG_MIN_ARGMAX and hard_agree >= BENCH_CFG_MIN_ARGMAX, (agree, hard_agree)
@@ -331,6 +378,8 @@ def test_cu_sharing_schedule_trains_like_the_default_one():
         kw = dict(join=(mode == "share+join"), split_reduce=(mode != "share-fused-sums"))
         if mode != "default":
             eng.set_cu_share(47.0, **kw)
+        else:
+            eng.set_cu_share(None)
         losses = []
         for i in range(4):
             if mode != "default" and i == 1:      # whatever the calibration decided, exercise the schedule
@@ -347,22 +396,28 @@ def test_cu_sharing_schedule_trains_like_the_default_one():
         assert runs[mode][-1] < runs[mode][0]
 
 
-def test_cu_sharing_calibration_reports_one_pair():
+def test_cu_sharing_is_the_default_and_its_calibration_reports_both_orders():
+    """WRNEngine turns the CU-sharing schedule on at construction; before the first backward() (or when called) the
+    calibration times one conv's backward in the default order and in the sharing order and reports both."""
     eng = E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=4)
+    assert eng._cu_share is not None and not eng._share_calibrated and eng.cu_share_report is None
     crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
                            hierarchy="induced-wrn28_10_cifar10")
     g = torch.Generator().manual_seed(9)
     x = torch.randn(128, 3, 32, 32, generator=g).to(DEV)
     y = torch.randint(0, 10, (128,), generator=g).to(DEV)
-    eng.set_cu_share(47.0)
-    assert eng.cu_share_report is None
     E.train_step(eng, crit, x, y, lr=0.02)
     rep = eng.cu_share_report
     print(rep)
     assert rep is not None and rep["pass_cus"] % 8 == 0 and 8 <= rep["pass_cus"] <= 128
     assert rep["pass_cus"] + rep["wgrad_cu_budget"] <= 256 + 8
-    assert rep["serial_us"] > 0 and rep["side_by_side_us"] > 0
-    assert rep["enabled"] == (eng._cu_share is not None)
+    assert rep["default_order_us"] > 0 and rep["sharing_order_us"] > 0 and "s1u" in rep["timed"]
+    assert rep["enabled"] == (eng._cu_share is not None) and eng._share_calibrated
+    # an explicit call re-measures; the fused-sums form is calibrated with its own kernels
+    eng.set_cu_share(47.0, split_reduce=False)
+    eng.forward(x, training=True)
+    rep2 = eng.calibrate_cu_share()
+    assert rep2["bn_sums"] == "data-gradient epilogue" and rep2["pass_cus"] <= rep["pass_cus"]
 
 
 def test_hipgraph_captured_step_equals_eager_steps():

@@ -50,6 +50,21 @@ const char* nbdt_last_error(void);
 const char* nbdt_debug_last_igemm(void);
 const char* nbdt_debug_last_wgrad(void);      /* same for nbdt_conv_wgrad */
 int nbdt_version(void);
+/* Deterministic mode (process-wide switch, default off).  The reference's CPU path (stock ATen ops,
+ * nbdt/models/resnet.py:69-74) gives the same bits on every run; the fast path does not: every cross-block fp32
+ * reduction of the backbone -- the 32 replicated BatchNorm accumulators (nbdt_bn_stats, nbdt_bn_bwd_reduce[_cus],
+ * nbdt_pool_bn_bwd_reduce), the split-K weight gradients (nbdt_conv_wgrad, nbdt_stem_wgrad, nbdt_linear_bwd) and the
+ * per-tile statistics of the conv epilogues (nbdt_conv_igemm_stats, nbdt_conv_igemm_bnbwd) -- goes through fp32
+ * atomics whose order changes from run to run, and a 1-ulp difference in a BatchNorm sum moves bf16 roundings and
+ * ReLU masks downstream (two runs of one WRN-28-10 step differ by ~0.17 relative L2 in the gradient).  With the switch
+ * on, each of those reductions adds into a zeroed, library-owned row per block / per pixel split (one add per address)
+ * and a fold kernel sums the rows in index order: two runs of the same launches on the same inputs are then
+ * bit-identical, whatever streams they were issued on.  Slower (an extra fold per reduction, 64+ MB of workspace per
+ * (device, stream), allocated with hipMalloc on first use -- not capturable in a hipGraph); the arithmetic differs
+ * from the default mode only in summation order.  Scope: the ResNet / WideResNet kernels and the rules layer (which
+ * has no atomics); the EfficientNet-specific kernels (nbdt_dwconv_*, nbdt_se_*, nbdt_bn_act_*) keep their atomics. */
+int nbdt_set_deterministic(int32_t on);
+int nbdt_get_deterministic(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int nbdt_device_count(void);
 

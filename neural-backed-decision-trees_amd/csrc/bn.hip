@@ -37,10 +37,12 @@ static int grid_for(const PadGeom& g, const Layout& l, int pixels_per_thread) {
 }
 
 // fold per-thread 8-channel partial sums across the PY pixel rows of the block, then add them
-// to slot (blockIdx & 31) of scratch[slot][which][C]
+// to slot (blockIdx & slot_mask) of scratch[slot][which][C].  slot_mask = kSlots - 1: the 32 replicated accumulators
+// (several blocks add to one slot, in whatever order they finish); slot_mask = ~0 (deterministic mode): `scratch` is
+// a zeroed row per BLOCK, every address receives exactly one add, and det_fold() sums the rows in block order.
 template <int NQ>
 __device__ __forceinline__ void block_fold_to_slots(float (&acc)[NQ][8], int cx, int py, int c8, int PY, int C,
-                                                    float* scratch, float* lds) {
+                                                    float* scratch, float* lds, unsigned slot_mask) {
   // lds: [PY][c8][NQ*8]
   float* mine = lds + ((size_t)py * c8 + cx) * (NQ * 8);
 #pragma unroll
@@ -53,12 +55,13 @@ __device__ __forceinline__ void block_fold_to_slots(float (&acc)[NQ][8], int cx,
     float s = 0.f;
     for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + cx) * (NQ * 8) + e];
     const int q = e >> 3, i = e & 7;
-    atomicAdd(scratch + ((size_t)(blockIdx.x & (kSlots - 1)) * NQ + q) * C + cx * 8 + i, s);
+    atomicAdd(scratch + ((size_t)(blockIdx.x & slot_mask) * NQ + q) * C + cx * 8 + i, s);
   }
 }
 
 __global__ __launch_bounds__(kMaxThreads) void bn_stats_kernel(const bf16_t* __restrict__ x, PadGeom g, int c8,
-                                                               int PY, float* __restrict__ scratch) {
+                                                               int PY, float* __restrict__ scratch,
+                                                               unsigned slot_mask) {
   extern __shared__ float lds[];
   const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
   float acc[2][8];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(kMaxThreads) void bn_stats_kernel(const bf16_t* __r
       acc[1][i] += f[i] * f[i];
     }
   }
-  block_fold_to_slots<2>(acc, cx, py, c8, PY, g.C, scratch, lds);
+  block_fold_to_slots<2>(acc, cx, py, c8, PY, g.C, scratch, lds, slot_mask);
 }
 
 // 1 block: fold slots; mode 0 = forward statistics, mode 1 = backward sums
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_reduce_kernel(const bf16_t
                                                                     const float* __restrict__ rstd,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, PadGeom g,
-                                                                    int c8, int PY, float* __restrict__ scratch) {
+                                                                    int c8, int PY, float* __restrict__ scratch,
+                                                                    unsigned slot_mask) {
   extern __shared__ float lds[];
   const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
   const bool maskx = POOL || (RELU && y == nullptr);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_reduce_kernel(const bf16_t
       acc[1][i] += gg * xh;
     }
   }
-  block_fold_to_slots<2>(acc, cx, py, c8, PY, g.C, scratch, lds);
+  block_fold_to_slots<2>(acc, cx, py, c8, PY, g.C, scratch, lds, slot_mask);
 }
 
 template <bool RELU, bool POOL, bool HAS_ADD, bool HAS_GRES>
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* _
                                                                  const float* __restrict__ rstd,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, PadGeom g, int c8,
-                                                                 int PY, float* __restrict__ scratch) {
+                                                                 int PY, float* __restrict__ scratch,
+                                                                 unsigned slot_mask) {
   extern __shared__ float lds[];
   const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
   const bool live = py < PY;               // (threads past the last whole pixel row idle, but join the block fold)
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* _
     const int ccx = e >> 4, k = e & 15;
     float s = 0.f;
     for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + ccx) * 16 + k];
-    atomicAdd(scratch + ((size_t)(blockIdx.x & (kSlots - 1)) * 2 + (k >> 3)) * g.C + ccx * 8 + (k & 7), s);
+    atomicAdd(scratch + ((size_t)(blockIdx.x & slot_mask) * 2 + (k >> 3)) * g.C + ccx * 8 + (k & 7), s);
   }
 }
 
@@ -448,6 +453,29 @@ static int check_shape(int B, int H, int W, int C) {
   return NBDT_OK;
 }
 
+
+// Where a reduction kernel of `grid` blocks adds its per-block sums of n = 2*C floats.  Normally the caller's 32-slot
+// scratch; in deterministic mode (nbdt_set_deterministic) a zeroed library-owned row per block -- each address then
+// receives exactly one atomic add -- that slot_finish() sums in block order into slot 0 of the caller's scratch, so
+// the finalize kernels (which fold the 32 slots in a fixed order anyway) need no second form.
+struct SlotTarget {
+  float* ptr;
+  unsigned mask;
+  bool det;
+};
+static int slot_target(hipStream_t st, float* scratch, int grid, size_t n, SlotTarget* t) {
+  t->ptr = scratch; t->mask = kSlots - 1; t->det = false;
+  if (!deterministic()) return NBDT_OK;
+  float* rows = det_rows(st, (size_t)grid * n);
+  if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+  NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)grid * n * sizeof(float), st));
+  t->ptr = rows; t->mask = ~0u; t->det = true;
+  return NBDT_OK;
+}
+static int slot_finish(hipStream_t st, const SlotTarget& t, int grid, size_t n, float* scratch) {
+  return t.det ? det_fold(st, t.ptr, grid, n, scratch) : NBDT_OK;
+}
+
 extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
                              float* running_mean, float* running_var, float* scratch, float* save_mean,
                              float* save_rstd, void* stream) {
@@ -460,9 +488,15 @@ extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int
   if (x != nullptr) {   // x == NULL: the producer (nbdt_dwconv_fwd with bn_scratch) already filled the slots
     const Layout l = layout_for(C);
     const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st, (const bf16_t*)x, g,
-                       l.c8, l.py, scratch);
+    const int grid = grid_for(g, l, 16);
+    SlotTarget t;
+    rc = slot_target(st, scratch, grid, 2 * (size_t)C, &t);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(l.threads), shmem, st, (const bf16_t*)x, g,
+                       l.c8, l.py, t.ptr, t.mask);
     NBDT_LAUNCH_CHECK();
+    rc = slot_finish(st, t, grid, 2 * (size_t)C, scratch);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, (float)g.npix, eps, momentum,
                      running_mean, running_var, save_mean, save_rstd);
@@ -606,16 +640,22 @@ extern "C" int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, 
   const PadGeom g = make_geom(B, H, W, C);
   const Layout l = layout_for(C);
   const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
-  const dim3 grid(grid_for(g, l, 16)), blk(l.threads);
+  const int nblk = grid_for(g, l, 16);
+  const dim3 grid(nblk), blk(l.threads);
+  SlotTarget t;
+  rc = slot_target(st, scratch, nblk, 2 * (size_t)C, &t);
+  if (rc) return rc;
   if (relu)
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), grid, blk, shmem, st, (const bf16_t*)gy, nullptr,
                        (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
-                       scratch);
+                       t.ptr, t.mask);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), grid, blk, shmem, st, (const bf16_t*)gy, nullptr,
                        (const bf16_t*)y, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
-                       scratch);
+                       t.ptr, t.mask);
   NBDT_LAUNCH_CHECK();
+  rc = slot_finish(st, t, nblk, 2 * (size_t)C, scratch);
+  if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
@@ -707,9 +747,14 @@ extern "C" int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float
   int blocks = cus;
   const int max_blocks = (g.npix + py - 1) / py;
   if (blocks > max_blocks) blocks = max_blocks;
+  SlotTarget t;
+  rc = slot_target(st, scratch, blocks, 2 * (size_t)C, &t);
+  if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_reduce_cus_kernel, dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
-                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, scratch);
+                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, t.ptr, t.mask);
   NBDT_LAUNCH_CHECK();
+  rc = slot_finish(st, t, blocks, 2 * (size_t)C, scratch);
+  if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
@@ -740,10 +785,16 @@ extern "C" int nbdt_pool_bn_bwd_reduce(const float* gpooled, const void* x, cons
   const PadGeom g = make_geom(B, H, W, C);
   const Layout l = layout_for(C);
   const size_t shmem = (size_t)l.threads * 16 * sizeof(float);
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(grid_for(g, l, 16)), dim3(l.threads), shmem, st,
+  const int nblk = grid_for(g, l, 16);
+  SlotTarget t;
+  rc = slot_target(st, scratch, nblk, 2 * (size_t)C, &t);
+  if (rc) return rc;
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(nblk), dim3(l.threads), shmem, st,
                      nullptr, gpooled, nullptr, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, l.c8, l.py,
-                     scratch);
+                     t.ptr, t.mask);
   NBDT_LAUNCH_CHECK();
+  rc = slot_finish(st, t, nblk, 2 * (size_t)C, scratch);
+  if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;

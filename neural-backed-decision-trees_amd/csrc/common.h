@@ -61,6 +61,16 @@ struct DeviceAttr {
     if (_e != hipSuccess) { (site).abort(); return nbdt::fail(NBDT_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); } \
   } while (0)
 
+// ---- deterministic mode (nbdt_set_deterministic; misc.hip).  Every cross-block fp32 reduction of the backbone
+// path normally goes through atomics (32 replicated BatchNorm slots, split-K weight gradients, LDS atomics in the conv
+// epilogue), whose order changes from run to run.  With the switch on, each of them adds into a zeroed library-owned
+// row per block / per pixel split instead -- one add per address -- and det_fold() sums the rows in index order.
+bool deterministic();
+// stream-ordered workspace of at least `floats` floats, one per (device, stream); nullptr if it cannot be allocated
+float* det_rows(hipStream_t st, size_t floats);
+// dst[i] += rows[0][i] + rows[1][i] + ... (ascending r, one thread per i), i < n
+int det_fold(hipStream_t st, const float* rows, int nrows, size_t n, float* dst);
+
 typedef unsigned short bf16_t;  // raw bf16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {

@@ -27,6 +27,7 @@ struct ConvDmaParams {
   int aff_act;         // 0 none, 1 ReLU, 2 swish
   int M, n_blocks, m_blocks, per_xcd;
   int overlap;         // conv3x3_pp_kernel: the epilogue's LDS is laid out around the next tile's first slice
+  int deterministic;   // nbdt_set_deterministic: the block's statistics are summed wave by wave, not with LDS atomics
 };
 }  // namespace nbdt
 
@@ -257,13 +258,28 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
     NBDT_EPI_STAMP(3 + 2 * tm)
   }
   if (STATS == 1 || STATS == 2) {
-    if (walker)
+    if (p.deterministic) {
+      // fixed order: wave 0's row lanes 0, 1, ..., then wave 1's, ... -- one turn per barrier, plain read-modify-write
+      // (lanes of one turn hold distinct channel chunks).  NWV * RL barriers per tile: a debugging mode, not a fast one.
+      for (int w = 0; w < NWV; ++w)
+        for (int r = 0; r < RL; ++r) {
+          if (wave == w && walker && rl == r)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        atomicAdd(blk_stats + ch * 8 + i, s1[i]);
-        atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
-      }
-    __syncthreads();
+            for (int i = 0; i < 8; ++i) {
+              blk_stats[ch * 8 + i] += s1[i];
+              blk_stats[BN + ch * 8 + i] += s2[i];
+            }
+          __syncthreads();
+        }
+    } else {
+      if (walker)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          atomicAdd(blk_stats + ch * 8 + i, s1[i]);
+          atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
+        }
+      __syncthreads();
+    }
     // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost
     // more than the separate statistics pass they replace); nbdt_bn_finalize folds the rows
     // (the fold kernels expect one row per 256 pixels: a 512-pixel tile fills row 2*m_blk and zeroes the next)

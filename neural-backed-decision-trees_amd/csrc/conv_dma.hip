@@ -214,6 +214,7 @@ int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void*
   p.aff_scale = bn ? bn->aff_scale : nullptr; p.aff_shift = bn ? bn->aff_shift : nullptr;
   p.aff_act = bn ? bn->aff_act : 0;
   p.M = M;
+  p.deterministic = deterministic() ? 1 : 0;
   const int nt32 = d->cout / 32;
   if (nt32 % 5 == 0) return launch_dma<5>(p, st);
   if (nt32 % 4 == 0) return launch_dma<4>(p, st);

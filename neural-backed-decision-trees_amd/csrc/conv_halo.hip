@@ -788,6 +788,7 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.aff_scale = bn ? bn->aff_scale : nullptr; p.aff_shift = bn ? bn->aff_shift : nullptr;
   p.aff_act = bn ? bn->aff_act : 0;
   p.M = M;
+  p.deterministic = deterministic() ? 1 : 0;
   const int nt = cout_tile(d->cout);
 #define NBDT_DISPATCH(KIND)                                     \
   {                                                             \

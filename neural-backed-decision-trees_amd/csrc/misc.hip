@@ -10,7 +10,57 @@
 // All HBM/latency-bound; none is on the MFMA critical path.
 #include "common.h"
 
+#include <atomic>
+#include <map>
+#include <utility>
+
 using namespace nbdt;
+
+// ------------------------------------------------------------------------------------------ deterministic mode
+namespace nbdt {
+static std::atomic<int> g_deterministic{0};
+bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+
+struct DetBuf { float* ptr = nullptr; size_t floats = 0; };
+static std::mutex g_det_mutex;
+static std::map<std::pair<int, hipStream_t>, DetBuf> g_det_bufs;
+
+float* det_rows(hipStream_t st, size_t floats) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_det_mutex);
+  DetBuf& b = g_det_bufs[std::make_pair(dev, st)];
+  if (b.floats < floats) {
+    // growing: the old buffer may still be read by work queued on this stream
+    if (b.ptr) { if (hipStreamSynchronize(st) != hipSuccess) return nullptr; (void)hipFree(b.ptr); b.ptr = nullptr; b.floats = 0; }
+    size_t want = floats < (16u << 20) ? (16u << 20) : floats + floats / 4;     // >= 64 MB, then 25 % headroom
+    if (hipMalloc((void**)&b.ptr, want * sizeof(float)) != hipSuccess) { b.ptr = nullptr; return nullptr; }
+    b.floats = want;
+  }
+  return b.ptr;
+}
+
+__global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__ rows, int nrows, size_t n,
+                                                       float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = dst[i];
+  for (int r = 0; r < nrows; ++r) s += rows[(size_t)r * n + i];      // fixed order: row 0, 1, 2, ...
+  dst[i] = s;
+}
+
+int det_fold(hipStream_t st, const float* rows, int nrows, size_t n, float* dst) {
+  hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, nrows, n, dst);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+}  // namespace nbdt
+
+extern "C" int nbdt_set_deterministic(int32_t on) {
+  nbdt::g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);
+  return NBDT_OK;
+}
+extern "C" int nbdt_get_deterministic(void) { return nbdt::deterministic() ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------ stem
 // thread = (pixel, 8-cout chunk); weights [cout][3][3][3] (co, r, s, ci) staged in LDS
@@ -52,7 +102,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // dw[co][27] += sum_pixels gy[pix][co] * img[tap]; block = pixel range, 64-pixel tiles in LDS
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gy,
                                                          int B, int H, int W, int cout, int cpad, int stride,
-                                                         int tiles_per_block, float* __restrict__ dw) {
+                                                         int tiles_per_block, float* __restrict__ dw,
+                                                         int row_stride) {
+  // row_stride: 0 = every block adds into dw; deterministic mode: cout*27, a zeroed row per block (det_fold sums them)
   extern __shared__ float lds[];  // gy tile [64][cout] then patch tile [64][27]
   float* gl = lds;
   float* pl = lds + 64 * cout;
@@ -99,7 +151,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int o = threadIdx.x + 256 * q;
-    if (o < nout) atomicAdd(dw + o, acc[q]);
+    if (o < nout) atomicAdd(dw + (size_t)blockIdx.x * row_stride + o, acc[q]);
   }
 }
 
@@ -127,9 +179,18 @@ extern "C" int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int3
   const int tpb = (tiles + blocks - 1) / blocks;
   blocks = (tiles + tpb - 1) / tpb;
   const size_t shmem = (size_t)(64 * cout_real + 64 * 27) * sizeof(float);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, img,
-                     (const bf16_t*)gy, B, H, W, cout_real, cpad, stride, tpb, dw);
+  hipStream_t st = (hipStream_t)stream;
+  const int nout = cout_real * 27;
+  float* target = dw;
+  if (deterministic()) {
+    target = det_rows(st, (size_t)blocks * nout);
+    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+    NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)blocks * nout * sizeof(float), st));
+  }
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), shmem, st, img,
+                     (const bf16_t*)gy, B, H, W, cout_real, cpad, stride, tpb, target, target == dw ? 0 : nout);
   NBDT_LAUNCH_CHECK();
+  if (target != dw) return det_fold(st, target, blocks, (size_t)nout, dw);
   return NBDT_OK;
 }
 
@@ -291,7 +352,7 @@ extern "C" int nbdt_linear_bwd(const float* x, const float* w, const float* gz, 
   }
   if (gw) {
     const long long n = (long long)N * (K + 1);
-    const int splits = B >= 64 ? 16 : 1;
+    const int splits = (B >= 64 && !deterministic()) ? 16 : 1;   // (one batch split: one add per address)
     const int bpb = (B + splits - 1) / splits;
     hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((n + 255) / 256), (B + bpb - 1) / bpb), dim3(256), 0, st, gz,
                        x, B, K, N, bpb, gw, gb);

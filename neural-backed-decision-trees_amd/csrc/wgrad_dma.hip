@@ -47,6 +47,7 @@ struct WgradDmaParams {
   const bf16_t* x;
   const bf16_t* gy;
   float* dw;
+  long long dw_split_stride;   // 0, or (deterministic mode) elements of dw: a zeroed copy per pixel split
   int M;               // pixels
   int chunks;          // ceil(M / 32)
   int chunks_per_split;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(nbdt::WgradDmaPa
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
-        atomicAdd(p.dw + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[a][b][r]);
+        atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[a][b][r]);
       }
     }
 }
@@ -275,8 +276,19 @@ static int launch_dma(WgradDmaParams& p, hipStream_t st) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     site.done(shmem);
   }
+  float* const dw = p.dw;
+  const size_t dw_elems = (size_t)p.d.cout * p.d.w_ntaps * p.d.cin;
+  p.dw_split_stride = 0;
+  if (deterministic()) {
+    float* rows = det_rows(st, (size_t)p.splits * dw_elems);
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-split gradients");
+    NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
+    p.dw = rows;
+    p.dw_split_stride = (long long)dw_elems;
+  }
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<WM, WN>), dim3(p.per_xcd * 8), dim3(256), shmem, st, p);
   NBDT_LAUNCH_CHECK();
+  if (p.dw != dw) return det_fold(st, p.dw, p.splits, dw_elems, dw);
   return NBDT_OK;
 }
 

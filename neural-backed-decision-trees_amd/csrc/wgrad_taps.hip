@@ -29,6 +29,8 @@ struct WgradTapsParams {
   const bf16_t* x;
   const bf16_t* gy;
   float* dw;
+  long long dw_split_stride;   // 0: every pixel split adds into dw; deterministic mode: elements of dw, a zeroed
+                               // copy per split (one add per address; det_fold sums the copies in split order)
   int stages;            // M / 32
   int stages_per_split;
   int n_ci_blocks;       // cin / 32
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void conv_wgrad_taps_ke
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
-        atomicAdd(p.dw + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
+        atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
       }
   }
 }
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
-          atomicAdd(p.dw + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
+          atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
         }
     }
   };
@@ -675,9 +677,20 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
     NBDT_ATTR_CHECK(site, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     site.done(shmem);
   }
+  float* const dw = p.dw;
+  const size_t dw_elems = (size_t)p.d.cout * p.d.w_ntaps * p.d.cin;
+  p.dw_split_stride = 0;
+  if (deterministic()) {
+    float* rows = det_rows(st, (size_t)p.splits * dw_elems);
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-split gradients");
+    NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
+    p.dw = rows;
+    p.dw_split_stride = (long long)dw_elems;
+  }
   void* args[] = {(void*)&p};
   NBDT_HIP_CHECK(hipLaunchKernel(fn, dim3(p.per_xcd * 8), dim3(PP ? 512 : 256), args, shmem, st));
   g_last_wgrad = PP ? "conv_wgrad_pp_kernel" : "conv_wgrad_taps_kernel";
+  if (p.dw != dw) return det_fold(st, p.dw, p.splits, dw_elems, dw);
   return NBDT_OK;
 }
 

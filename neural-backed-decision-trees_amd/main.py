@@ -101,6 +101,9 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="number of synthetic training samples")
     p.add_argument("--image-size", type=int, default=0, help="synthetic image size (default: dataset's)")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--deterministic", action="store_true",
+                   help="bit-reproducible training steps, like the reference's CPU path: every cross-block reduction in "
+                        "a fixed order instead of fp32 atomics (nbdt_set_deterministic; ResNet / WideResNet backbones)")
     return p
 
 
@@ -238,6 +241,9 @@ def main(argv=None):
         f"{test_x.shape[0]} test samples of shape {tuple(train_x.shape[1:])}")
 
     log("==> Building model..")
+    if args.deterministic:
+        from nbdt import ops
+        ops.set_deterministic(True)
     net = getattr(models, args.arch)(num_classes=num_classes, device=device, seed=args.seed)
     engine = net.engine
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "nbdt_last_error": (c_char_p, []),
     "nbdt_version": (c_int, []),
     "nbdt_device_count": (c_int, []),
+    "nbdt_set_deterministic": (c_int, [c_int32]),
+    "nbdt_get_deterministic": (c_int, []),
     "nbdt_tree_create": (c_int, [c_int, c_int, c_int, c_int, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P,
                                  POINTER(c_void_p)]),
     "nbdt_tree_destroy": (c_int, [c_void_p]),

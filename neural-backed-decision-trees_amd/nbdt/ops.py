@@ -21,6 +21,17 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+def set_deterministic(on):
+    """Process-wide: every cross-block reduction of the ResNet / WideResNet path in a fixed order instead of fp32
+    atomics (nbdt_set_deterministic in include/nbdt_hip.h) -- same launches + same inputs => same bits, like the
+    reference's CPU path.  Slower; for parity runs and debugging."""
+    check(lib().nbdt_set_deterministic(1 if on else 0))
+
+
+def is_deterministic():
+    return bool(lib().nbdt_get_deterministic())
+
+
 def padded(B, H, W, C, device):
     """Zero-initialised padded NHWC bf16 activation buffer."""
     return torch.zeros((B, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)

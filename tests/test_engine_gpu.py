@@ -126,17 +126,25 @@ def test_wrn_forward_backward_matches_fp32_oracle(pkg_dir):
     print(f"worst per-tensor gradient rel-L2 error: {worst:.4f}")
 
 
-@pytest.mark.parametrize("blocks,width,B", [(10, 2, 16), (28, 10, 128)])
-def test_every_op_is_self_consistent(blocks, width, B, pkg_dir):
+@pytest.mark.parametrize("blocks,width,B,schedule", [(10, 2, 16, "auto"), (28, 10, 128, "default"),
+                                                     (28, 10, 512, "cu-share-split")])
+def test_every_op_is_self_consistent(blocks, width, B, schedule, pkg_dir):
     """Element-level parity on REAL network tensors: every kernel's output is recomputed with the
     plain fp32 PyTorch op from the engine's OWN stored inputs (so no cross-implementation ReLU-mask
     chaos) and must match within bf16 storage rounding (relative L2 < 1%).  The second case is the benched
     network itself, WRN-28-10, at a batch (128) whose stage-1 launches select the 512-pixel ping-pong kernel and
-    whose stage-2/3 launches the 256-pixel one."""
+    whose stage-2/3 launches the 256-pixel one, in the default schedule (fused-sums data gradients); the third is
+    the BENCHED configuration in the BENCHED schedule: 512 images, every dense conv on the 8-wave kernels, plain-
+    epilogue data gradients, nbdt_bn_bwd_reduce_cus / _apply_cus on 56-112 CUs beside the CU-budgeted weight
+    gradients on the second stream (about a minute of host time for the fp32 recomputation)."""
     import torch.nn.functional as F
     from nbdt import ops
     eng = E.WRNEngine(num_classes=10, blocks=blocks, width_factor=width, device=DEV, seed=7)
     eng.debug_keep = True
+    if schedule == "default":
+        eng.set_cu_share(None)
+    elif schedule == "cu-share-split":
+        eng.set_cu_share(47.0, calibrate=False)
     crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
                            hierarchy="induced-wrn28_10_cifar10")
     g = torch.Generator().manual_seed(4)

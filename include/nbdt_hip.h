@@ -115,6 +115,20 @@ int nbdt_soft_backward(const nbdt_tree* t, const void* z, int ztype, int64_t B, 
 int nbdt_soft_tree_loss(const nbdt_tree* t, const void* z, int ztype, int64_t B, int64_t ldz,
                         const int64_t* y, float w_xent, float w_tree, float grad_scale,
                         float* row_loss, float* loss, float* gz, void* stream);
+/* N1 -- classifier head + SoftTreeSupLoss forward AND backward in one launch: the logits never touch HBM.
+ * Replaces nn.Linear (reference nbdt/models/resnet.py:126,148; pytorchcv `output`), TreeSupLoss.forward with the soft
+ * rules (nbdt/loss.py:191-203, 264-266; nbdt/model.py:94-99, 207-242) and the Linear's autograd, i.e. the sequence
+ * nbdt_linear_fwd -> nbdt_soft_tree_loss -> nbdt_linear_bwd, for classifiers of at most 512 classes / child slots
+ * (NBDT_EINVAL beyond: use that sequence).
+ *   pooled [B][K] fp32 features, W [C][K], bias [C] (nullable) fp32;  z = pooled W^T + bias (one wave per class,
+ *   lanes over K, fused multiply-adds + xor butterfly: bit-identical to nbdt_linear_fwd for C < 64);
+ *   loss / row_loss as nbdt_soft_tree_loss;  z_out [B][C] (nullable) = the logits the loss was computed on;
+ *   gpooled [B][K] (nullable) = dL/dpooled;  gW [C][K], gb [C] (nullable) ACCUMULATE dL/dW, dL/db (+=). */
+int nbdt_head_soft_tree_loss(const nbdt_tree* t, const float* pooled, const float* W, const float* bias, int64_t B,
+                             int32_t K, const int64_t* y, float w_xent, float w_tree, float grad_scale,
+                             float* row_loss, float* loss, float* z_out, float* gpooled, float* gW, float* gb,
+                             void* stream);
+
 /* HardTreeSupLoss.forward + backward fused (nbdt/loss.py:191-203, 212-257; label filtering
  * nbdt/model.py:127-143) for criterion = nn.CrossEntropyLoss():
  *   loss = mean_b[ w_xent*CE(z_b,y_b) + w_node * sum_{inner nodes n with y_b under n}

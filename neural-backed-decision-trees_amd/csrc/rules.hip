@@ -601,29 +601,18 @@ __global__ __launch_bounds__(block_of(TPS)) void soft_bwd_kernel(TreeView t, con
 // SoftTreeSupLoss forward+backward for criterion = nn.CrossEntropyLoss() (mean reduction):
 //   row = w_x*(lse(z) - z[y]) + w_t*(lse(P) - P[y])     (P fed to CE as if logits, loss.py:266)
 //   gz  = scale*( w_x*(softmax(z) - 1[y]) + J^T * w_t*(softmax(P) - 1[y]) )
-template <int TPS, typename LD>
-__global__ __launch_bounds__(block_of(TPS)) void soft_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
-                                                           const int64_t* __restrict__ y, float w_x,
-                                                           float w_t, float scale,
-                                                           float* __restrict__ row_loss,
-                                                           float* __restrict__ gz) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int SPB = block_of(TPS) / TPS;
-  const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
-  const int64_t sample = (int64_t)blockIdx.x * SPB + g;
-  const bool active = sample < B;
-  const int stride = 3 * t.C + 2 * t.R + 16 + (t.staged ? t.L : 0);
-  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
-  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
-  const TreeLds o = stage_tree<false>(t, lds);
-  float* zs = lds + t.tl_ints + (size_t)g * stride;
-  float* ss = zs + t.C;
-  float* ps = ss + t.R;
-  float* pq = ps + t.R;
-  float* gx = pq + t.C;
-  float* red = gx + t.C;
-  float* stage = red + 16;
-  load_and_node_logits<TPS, LD>(t, o, z, sample * ldz, active, g_tid, zs, ss, stage, ga, gb, t.cls_slot);
+// Everything after the sample's logits are in LDS (zs, published by a __syncthreads()) -- shared by soft_loss_kernel,
+// which loads them from HBM, and head_soft_loss_kernel, which computes them from the pooled features.  On return
+// gx[c] holds dL/dz[c] for every class (each written by the lane that owns c; no trailing barrier); gz != nullptr
+// also stores it to gz[sample][c].
+template <int TPS>
+__device__ __forceinline__ void soft_loss_from_lds_logits(const TreeView& t, const TreeLds& o, bool active, int g_tid,
+                                                          int64_t sample, const int64_t* __restrict__ y, float w_x,
+                                                          float w_t, float scale, float* __restrict__ row_loss,
+                                                          float* zs, float* ss, float* ps, float* pq, float* gx,
+                                                          float* red, float* stage, Gather<TPS>& ga, Gather<TPS>& gb,
+                                                          float* __restrict__ gz) {
+  slot_sums<TPS, true>(t, o, zs, stage, ss, active, g_tid, ga, gb, t.cls_slot);
   node_softmax<TPS>(t, o, active, g_tid, ss, ps);
   stage_paths<TPS>(t, ps, stage, g_tid, gb);
   if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);  // for the G sums of tree_backward
@@ -674,9 +663,138 @@ __global__ __launch_bounds__(block_of(TPS)) void soft_loss_kernel(TreeView t, co
       float d[joint_of<TPS>()];
       class_chains<TPS, ChainAdd>(t, o, c0, ss, stage, 0.f, d);
 #pragma unroll
-      for (int m = 0; m < joint_of<TPS>(); ++m)
-        if (c0 + m * TPS < t.C) gz[sample * t.C + c0 + m * TPS] = gx[c0 + m * TPS] + d[m];
+      for (int m = 0; m < joint_of<TPS>(); ++m) {
+        const int c = c0 + m * TPS;
+        if (c < t.C) {
+          const float v = gx[c] + d[m];
+          gx[c] = v;
+          if (gz) gz[sample * t.C + c] = v;
+        }
+      }
     }
+}
+
+template <int TPS, typename LD>
+__global__ __launch_bounds__(block_of(TPS)) void soft_loss_kernel(TreeView t, const void* z, int64_t B, int64_t ldz,
+                                                           const int64_t* __restrict__ y, float w_x,
+                                                           float w_t, float scale,
+                                                           float* __restrict__ row_loss,
+                                                           float* __restrict__ gz) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SPB = block_of(TPS) / TPS;
+  const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
+  const int64_t sample = (int64_t)blockIdx.x * SPB + g;
+  const bool active = sample < B;
+  const int stride = 3 * t.C + 2 * t.R + 16 + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gb;  // ga: slot -> classes (issued here, under the logits load), gb: class -> slots
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* zs = lds + t.tl_ints + (size_t)g * stride;
+  float* ss = zs + t.C;
+  float* ps = ss + t.R;
+  float* pq = ps + t.R;
+  float* gx = pq + t.C;
+  float* red = gx + t.C;
+  float* stage = red + 16;
+  if (active)
+    for (int c = g_tid; c < t.C; c += TPS) zs[c] = LD::at(z, sample * ldz + c);
+  __syncthreads();
+  soft_loss_from_lds_logits<TPS>(t, o, active, g_tid, sample, y, w_x, w_t, scale, row_loss, zs, ss, ps, pq, gx, red,
+                                 stage, ga, gb, gz);
+}
+
+// ---- N1: the classifier head and the tree loss in ONE launch (north star: "the node-embedding inner product and
+// per-node softmax / path-product as a fused wavefront-reduction kernel with coalesced HBM reads of the (batch x
+// feature) x (nodes x feature) matrices").  Replaces, for a classifier of at most 512 classes,
+//     nbdt_linear_fwd -> nbdt_soft_tree_loss -> nbdt_linear_bwd      (nn.Linear, reference nbdt/models/resnet.py:126,148 /
+//                                                                    pytorchcv `output`; nbdt/loss.py:191-203, 264-266)
+// The logits never touch HBM (unless z_out asks for them).  Per sample (a group of TPS lanes, as in every kernel of
+// this file):  pooled row -> LDS;  z[c] = sum_k x[k] W[c][k] + b[c] with ONE WAVE PER CLASS -- lanes stride the
+// feature axis (coalesced 256-byte reads of a W row), fused multiply-adds, xor-butterfly -- i.e. the arithmetic of
+// linear_fwd_kernel (misc.hip), so the logits are bit-identical to the unfused path's for heads below 64 classes;
+// then the ordered-chain rules + loss above on those logits in LDS (node logits / decisions bit-exact against the
+// oracle on the logits z_out reports);  then the head's backward from the same block:
+//     dpooled[b][k] = sum_c gz[c] W[c][k]              (ascending c, fused multiply-adds: linear_bwd_x_kernel's order)
+//     dW[c][k] += sum over the block's SPB samples of gz[c] x[k],  db[c] += sum of gz[c]   (one add per block and
+//     address; deterministic mode: a zeroed row per block, summed in block order by det_fold).
+template <int TPS, int SPB>
+__global__ __launch_bounds__(TPS * SPB) void head_soft_loss_kernel(TreeView t, const float* __restrict__ pooled,
+                                                                   const float* __restrict__ W,
+                                                                   const float* __restrict__ bias, int K, int64_t B,
+                                                                   const int64_t* __restrict__ y, float w_x, float w_t,
+                                                                   float scale, float* __restrict__ row_loss,
+                                                                   float* __restrict__ z_out,
+                                                                   float* __restrict__ gpooled, float* gW, float* gb,
+                                                                   long long row_stride_w, long long row_stride_b) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int g = threadIdx.x / TPS, g_tid = threadIdx.x % TPS;
+  const int64_t sample = (int64_t)blockIdx.x * SPB + g;
+  const bool active = sample < B;
+  const int stride = K + 3 * t.C + 2 * t.R + 16 + (t.staged ? t.L : 0);
+  Gather<TPS> ga, gbk;
+  if (t.staged) ga.issue(t.slot_cls, t.L, active, g_tid);
+  const TreeLds o = stage_tree<false>(t, lds);
+  float* rows = lds + t.tl_ints;
+  float* xs = rows + (size_t)g * stride;
+  float* zs = xs + K;
+  float* ss = zs + t.C;
+  float* ps = ss + t.R;
+  float* pq = ps + t.R;
+  float* gx = pq + t.C;
+  float* red = gx + t.C;
+  float* stage = red + 16;
+  if (active)
+    for (int k = g_tid; k < K; k += TPS) xs[k] = pooled[sample * K + k];
+  __syncthreads();
+  {  // classifier forward: wave wv of the group takes classes wv, wv + NW, ...
+    constexpr int NW = TPS / 64;
+    const int wv = g_tid >> 6, lane = g_tid & 63;
+    if (active)
+      for (int c = wv; c < t.C; c += NW) {
+        const float* wr = W + (size_t)c * K;
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s = fmaf(xs[k], wr[k], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+          const float zc = s + (bias ? bias[c] : 0.f);
+          zs[c] = zc;
+          if (z_out) z_out[sample * t.C + c] = zc;
+        }
+      }
+  }
+  __syncthreads();
+  soft_loss_from_lds_logits<TPS>(t, o, active, g_tid, sample, y, w_x, w_t, scale, row_loss, zs, ss, ps, pq, gx, red,
+                                 stage, ga, gbk, nullptr);
+  __syncthreads();      // every sample's gx is complete: the block-wide weight-gradient sums read all of them
+  if (active && gpooled)
+    for (int k = g_tid; k < K; k += TPS) {
+      float s = 0.f;
+      for (int c = 0; c < t.C; ++c) s = fmaf(gx[c], W[(size_t)c * K + k], s);
+      gpooled[sample * K + k] = s;
+    }
+  if (gW) {
+    const int n_live = (int)((B - (int64_t)blockIdx.x * SPB) < SPB ? (B - (int64_t)blockIdx.x * SPB) : SPB);
+    const int gx_off = (int)(gx - xs);
+    float* dw = gW + (size_t)blockIdx.x * row_stride_w;
+    for (int idx = threadIdx.x; idx < t.C * K; idx += TPS * SPB) {
+      const int c = idx / K, k = idx - c * K;
+      float s = 0.f;
+      for (int j = 0; j < n_live; ++j) {
+        const float* xr = rows + (size_t)j * stride;
+        s = fmaf(xr[gx_off + c], xr[k], s);
+      }
+      atomicAdd(dw + idx, s);
+    }
+    if (gb) {
+      float* db = gb + (size_t)blockIdx.x * row_stride_b;
+      for (int c = threadIdx.x; c < t.C; c += TPS * SPB) {
+        float s = 0.f;
+        for (int j = 0; j < n_live; ++j) s += rows[(size_t)j * stride + gx_off + c];
+        atomicAdd(db + c, s);
+      }
+    }
+  }
 }
 
 // HardTreeSupLoss forward+backward for criterion = nn.CrossEntropyLoss() (nbdt/loss.py:212-257):
@@ -1152,6 +1270,67 @@ extern "C" int nbdt_soft_tree_loss(const nbdt_tree* t, const void* z, int ztype,
   NBDT_DISPATCH_RULES(soft_loss_kernel, false, 3 * t->C + 2 * t->R + 16, v, z, B, ldz, y, w_xent, w_tree, scale,
                       row_loss, gz);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, row_loss, B, loss);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+template <int TPS, int SPB>
+static int launch_head(const nbdt_tree* t, TreeView v, const float* pooled, const float* W, const float* bias, int K,
+                       int64_t B, const int64_t* y, float w_x, float w_t, float scale, float* row_loss, float* z_out,
+                       float* gpooled, float* gW, float* gb, hipStream_t st) {
+  size_t floats = (size_t)K + 3 * (size_t)t->C + 2 * (size_t)t->R + 16;
+  v.tl_ints = tree_lds_ints(t, false);
+  v.staged = ((size_t)v.tl_ints + (size_t)SPB * (floats + t->L) + kStagePad) * sizeof(float) <= kLdsBytes;
+  if (v.staged) floats += t->L;
+  const size_t shmem = ((size_t)v.tl_ints + (size_t)SPB * floats + kStagePad) * sizeof(float);
+  if (shmem > kLdsBytes) return 1;     // caller tries fewer samples per block
+  const unsigned grid = (unsigned)((B + SPB - 1) / SPB);
+  float *dw = gW, *db = gb, *rows = nullptr;
+  long long sw = 0, sb = 0;
+  const size_t nw = (size_t)t->C * K, nb = (size_t)t->C;
+  if (gW && deterministic()) {       // a zeroed row per block for dW and db, folded in block order afterwards
+    rows = det_rows(st, (size_t)grid * (nw + nb));
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+    NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)grid * (nw + nb) * sizeof(float), st));
+    dw = rows; db = gb ? rows + (size_t)grid * nw : nullptr;
+    sw = (long long)nw; sb = (long long)nb;
+  }
+  int rc = launch_rules(head_soft_loss_kernel<TPS, SPB>, grid, TPS * SPB, shmem, st, v, pooled, W, bias, K, B, y, w_x,
+                        w_t, scale, row_loss, z_out, gpooled, dw, db, sw, sb);
+  if (rc) return rc;
+  if (rows) {
+    rc = det_fold(st, rows, (int)grid, nw, gW);
+    if (rc) return rc;
+    if (gb) rc = det_fold(st, rows + (size_t)grid * nw, (int)grid, nb, gb);
+  }
+  return rc;
+}
+
+extern "C" int nbdt_head_soft_tree_loss(const nbdt_tree* t, const float* pooled, const float* W, const float* bias,
+                                        int64_t B, int32_t K, const int64_t* y, float w_xent, float w_tree,
+                                        float grad_scale, float* row_loss, float* loss, float* z_out, float* gpooled,
+                                        float* gW, float* gb, void* stream) {
+  NBDT_REQUIRE(t != nullptr, "null tree handle");
+  NBDT_REQUIRE(pooled && W && y && row_loss && loss, "null buffer");
+  NBDT_REQUIRE(B > 0, "empty batch has no mean loss");
+  NBDT_REQUIRE(K > 0 && K <= 4096, "feature width must be 1..4096");
+  NBDT_REQUIRE(gW != nullptr || gb == nullptr, "db without dW is not supported");
+  const int tps = pick_tps(t);
+  NBDT_REQUIRE(tps <= 256, "classifier too wide for the fused head (more than 512 classes or child slots): use "
+                           "nbdt_linear_fwd + nbdt_soft_tree_loss + nbdt_linear_bwd");
+  TreeView v = view_of(t);
+  const float scale = grad_scale / (float)B;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 1;
+#define NBDT_HEAD(TPS_, SPB_)                                                                                      \
+  if (rc == 1) rc = launch_head<TPS_, SPB_>(t, v, pooled, W, bias, K, B, y, w_xent, w_tree, scale, row_loss, z_out, \
+                                            gpooled, gW, gb, st)
+  if (tps == 64) { NBDT_HEAD(64, 16); NBDT_HEAD(64, 8); NBDT_HEAD(64, 4); NBDT_HEAD(64, 1); }
+  else { NBDT_HEAD(256, 4); NBDT_HEAD(256, 2); NBDT_HEAD(256, 1); }
+#undef NBDT_HEAD
+  NBDT_REQUIRE(rc != 1, "hierarchy + feature row too large for LDS");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, st, row_loss, B, loss);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

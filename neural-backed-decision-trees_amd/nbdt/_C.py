@@ -72,6 +72,8 @@ SIGNATURES = {
     "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,
                                     _P, _P, _P, _P]),
+    "nbdt_head_soft_tree_loss": (c_int, [c_void_p, _P, _P, _P, c_int64, c_int32, _P, c_float, c_float, c_float,
+                                         _P, _P, _P, _P, _P, _P, _P]),
     "nbdt_hard_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,
                                     _P, _P, _P, _P]),
     "nbdt_node_logits_backward": (c_int, [c_void_p, _P, c_int64, _P, _P]),
@@ -260,6 +262,29 @@ def soft_tree_loss(handle, z, y, w_xent, w_tree, grad_scale=1.0):
                                     float(w_tree), float(grad_scale), ptr(row), ptr(loss), ptr(gz),
                                     stream_of(z)))
     return loss, gz
+
+
+def head_soft_tree_loss(handle, pooled, W, bias, y, w_xent, w_tree, grad_scale=1.0, gW=None, gb=None,
+                        want_logits=False, want_gpooled=True):
+    """Classifier head + SoftTreeSupLoss forward and backward in ONE launch (nbdt_head_soft_tree_loss): returns
+    (loss, dL/dpooled or None, logits or None); dL/dW and dL/db are ACCUMULATED into gW / gb when given."""
+    require_gpu(pooled, "head_soft_tree_loss")
+    handle.flat.require_single_path()
+    if pooled.dtype != torch.float32 or W.dtype != torch.float32 or not pooled.is_contiguous() or not W.is_contiguous():
+        raise NBDTHipError("head_soft_tree_loss takes contiguous fp32 features [B, K] and weights [C, K]")
+    B, K = pooled.shape
+    C = handle.flat.num_classes
+    if tuple(W.shape) != (C, K):
+        raise NBDTHipError(f"classifier weight is {tuple(W.shape)}, the hierarchy has {C} classes over {K} features")
+    y = _class_targets(y, pooled)
+    row = torch.empty((B,), dtype=torch.float32, device=pooled.device)
+    loss = torch.empty((), dtype=torch.float32, device=pooled.device)
+    z = torch.empty((B, C), dtype=torch.float32, device=pooled.device) if want_logits else None
+    gp = torch.empty((B, K), dtype=torch.float32, device=pooled.device) if want_gpooled else None
+    check(lib().nbdt_head_soft_tree_loss(handle.h, ptr(pooled), ptr(W), ptr(bias), B, K, ptr(y), float(w_xent),
+                                         float(w_tree), float(grad_scale), ptr(row), ptr(loss), ptr(z), ptr(gp),
+                                         ptr(gW), ptr(gb), stream_of(pooled)))
+    return loss, gp, z
 
 
 def hard_tree_loss(handle, z, y, w_xent, w_node, grad_scale=1.0):

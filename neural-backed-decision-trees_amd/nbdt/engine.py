@@ -161,7 +161,7 @@ class Conv:
         B, Hp, Wp, _ = x.shape
         side = getattr(self, "side_stream", None)
         if side is None:
-            ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name))
+            ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name), cu_budget)
             return
         # the weight gradient only feeds the optimizer, so it runs on a second stream next to the
         # data-gradient chain (see WRNEngine.backward for the buffer-reuse ordering)
@@ -255,6 +255,7 @@ class _Engine:
         self.training = True
         self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
         self.debug_share_serial = False   # tests: the CU-sharing schedule's exact launches (CU counts, budgets) on ONE stream
+        self.debug_join_each_unit = False # A/B: join the side stream at the top of every unit (the schedule before round 3)
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
@@ -391,7 +392,7 @@ class _Engine:
         h, w = x_out.shape[1] - 2, x_out.shape[2] - 2
         conv, bn = u["conv2"], u["bn2"]
         a2, t = self.buf(k + ".a2", B, h, w, cout), self.buf(k + ".t", B, h, w, cout)
-        ga2, gt = self.buf(f"ga2_{cout}", B, h, w, cout), self.buf(f"gt_{cout}", B, h, w, cout)
+        ga2, gt = self.buf(f"ga2_{cout}", B, h, w, cout), self.buf(f"gt_{cout}_0", B, h, w, cout)
         g = self.buf(f"g_in{cout}_{h}_0", B, h, w, cout)      # backward() rewrites all three before it reads them
         ops.interior(g).normal_(0.0, 1e-3)                    # (plumbing: a one-off fill so the MFMAs see real data)
         split, split_us = self._share_split
@@ -651,7 +652,11 @@ class WRNEngine(_Engine):
         return None
 
     # ------------------------------------------------------------------ forward / backward
-    def forward(self, img, training=None):
+    classifier_names = ("output.weight", "output.bias")
+
+    def forward(self, img, training=None, head=True):
+        """head=False: stop at the pooled features [B, feat_c] (fp32) -- the caller runs the classifier inside the
+        fused head + loss kernel (train_step) and hands dL/dpooled to backward(gpooled=...)."""
         training = self.training if training is None else training
         if img.dtype != torch.float32 or not img.is_contiguous():
             img = img.float().contiguous()
@@ -693,6 +698,8 @@ class WRNEngine(_Engine):
         self._pooled = self._tensor("pooled", (B, self.feat_c))
         ops.bn_relu_pool(x, self.post_bn.mean, self.post_bn.rstd, self.post_bn.gamma, self.post_bn.beta,
                          self._pooled)
+        if not head:
+            return self._pooled
         z = self._tensor("z", (B, self.num_classes))
         ops.linear_fwd(self._pooled, self.store.p("output.weight"), self.store.p("output.bias"), z)
         return z
@@ -705,32 +712,52 @@ class WRNEngine(_Engine):
         s3 = ent["features.stage3.unit1.body.conv1.bn.weight"][0]
         return [(s3, self.store.grad.numel()), (s2, s3), (0, s2)]
 
-    def backward(self, gz, comm=None):
-        """Accumulates d(loss)/d(params) into the flat gradient buffer given gz = dloss/dz [B, classes].
-        With a GradComm, each stage's gradient bucket is all-reduced as soon as it is complete."""
+    def backward(self, gz, comm=None, gpooled=None):
+        """Accumulates d(loss)/d(params) into the flat gradient buffer given gz = dloss/dz [B, classes] -- or, after
+        forward(head=False), given gpooled = dloss/dpooled [B, feat_c] (the fused head kernel already accumulated the
+        classifier's gradients).  With a GradComm, each stage's gradient bucket is all-reduced as soon as it is
+        complete."""
         B = self._B
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         if self._cu_share is not None and not self._share_calibrated:
             self.calibrate_cu_share(comm)      # once per set_cu_share(): keep the sharing only if it is faster here
         two_streams = self._side is not None and self._overlap
         buckets = self.grad_buckets() if comm is not None else None
-        gz = gz.contiguous()
         st = self.store
-        gpool = self._tensor("gpool", (B, self.feat_c))
-        ops.linear_bwd(self._pooled, st.p("output.weight"), gz, gpool, st.g("output.weight"), st.g("output.bias"))
+        if gpooled is not None:
+            gpool = gpooled
+        else:
+            gz = gz.contiguous()
+            gpool = self._tensor("gpool", (B, self.feat_c))
+            ops.linear_bwd(self._pooled, st.p("output.weight"), gz, gpool, st.g("output.weight"), st.g("output.bias"))
         h, w = self._hw
         C = _pad32(self.feat_c)
         g = self.buf(f"g_out{C}", B, h, w, C)
         pb = self.post_bn
         ops.pool_bn_bwd(gpool, self._x_last, pb.mean, pb.rstd, pb.gamma, pb.beta, self.scratch(C), pb.dsum,
                         st.g(pb.name + ".weight"), st.g(pb.name + ".bias"), g)
-        toggle = 0
+        toggle, n_unit, side_mark = 0, 0, None
+        if two_streams:      # (also forks the side stream into a hipGraph capture before its first event is recorded)
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
         for u in reversed(self.units):
-            # Gradient buffers are shared between units (gt_*, the two g_in_* ping-pong buffers): a weight
-            # gradient of the PREVIOUS unit still running on the side stream may be reading what this unit is
-            # about to overwrite.  Joining here orders it first; it was issued a whole unit (~0.9 ms) ago and
-            # takes ~0.25 ms, so the wait is free.  Inside one unit no kernel overwrites a wgrad operand.
-            self.join_side_stream()
+            # Gradient buffers are shared between units, and a weight gradient still running on the side stream may be
+            # reading what a later unit is about to overwrite: conv1's reads `gt`, conv2's the unit's output gradient
+            # (the previous unit's g_in).  Joining the side stream here would order that, but it makes the main
+            # stream wait for the weight gradient issued LAST (the previous unit's conv1, ~70 us of a 1 ms unit with
+            # 96 CUs idle: 0.95 ms of launch gaps per backward in profiles/r03_split_*two_streams*).  Instead the
+            # main stream waits for everything the side stream had been given ONE UNIT AGO (an event recorded at the
+            # top of the previous unit), and the buffers a weight gradient of the previous unit can still be reading
+            # are not the ones this unit writes: `gt` alternates between two buffers, g_in rotates through three.
+            # (tests/test_engine_gpu.py::test_deterministic_mode_makes_the_schedules_bit_comparable: this schedule
+            # gives the same bits as one stream with private buffers.)
+            if two_streams and self.debug_join_each_unit:
+                self.join_side_stream()
+            elif two_streams:
+                main = torch.cuda.current_stream(self.device)
+                if side_mark is not None:
+                    main.wait_event(side_mark)
+                side_mark = torch.cuda.Event()
+                side_mark.record(self._side)
             k, s = u["key"], u["stride"]
             cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
             ho, wo = h, w
@@ -740,10 +767,11 @@ class WRNEngine(_Engine):
             a2 = self.buf(k + ".a2", B, ho, wo, cout)
             tag = ("@" + k) if self.debug_keep else ""
             ga2 = self.buf(f"ga2_{cout}{tag}", B, ho, wo, cout)
-            gt = self.buf(f"gt_{cout}{tag}", B, ho, wo, cout)
+            gt = self.buf(f"gt_{cout}_{n_unit & 1}{tag}", B, ho, wo, cout)
             ga1 = self.buf(f"ga1_{cin}_{hi}{tag}", B, hi, wi, cin)
-            # ping-pong: the unit's input gradient must not alias its output gradient `g`
-            toggle ^= 1
+            # the unit's input gradient must not alias its output gradient `g` (nor, see above, the one before that)
+            toggle = (toggle + 1) % 3
+            n_unit += 1
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             u["dbg"] = {"g_out": g, "ga2": ga2, "gt": gt, "ga1": ga1, "g_in": g_in}
             fuse = self.fuse_stats
@@ -797,7 +825,7 @@ class WRNEngine(_Engine):
                 n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 4) if share else 0
                 u["bn1"].backward_fused(ga1, x_in, g_in, self.partials(x_in), gx_add=g, cus=n1)
                 g, h, w = g_in, hi, wi
-                continue      # (the join at the top of the next unit orders this weight gradient)
+                continue
             u["conv1"].backward_weight(a1, gt)
             u["conv1"].backward_data(gt, ga1)
             if u["idconv"] is not None:
@@ -885,7 +913,9 @@ class ResNetEngine(_Engine):
         l2 = ent["layer2.0.conv1.weight"][0]
         return [(l3, self.store.grad.numel()), (l2, l3), (0, l2)]
 
-    def forward(self, img, training=None):
+    classifier_names = ("linear.weight", "linear.bias")
+
+    def forward(self, img, training=None, head=True):
         training = self.training if training is None else training
         if img.dtype != torch.float32 or not img.is_contiguous():
             img = img.float().contiguous()
@@ -939,18 +969,23 @@ class ResNetEngine(_Engine):
         self._x_last, self._hw = x, (h, w)
         self._pooled = self._tensor("pooled", (B, self.feat_c))
         ops.bn_relu_pool(x, self._id_mean, self._id_rstd, self._id_gamma, self._id_beta, self._pooled)
+        if not head:
+            return self._pooled
         z = self._tensor("z", (B, self.num_classes))
         ops.linear_fwd(self._pooled, self.store.p("linear.weight"), self.store.p("linear.bias"), z)
         return z
 
-    def backward(self, gz, comm=None):
+    def backward(self, gz, comm=None, gpooled=None):
         B = self._B
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
-        gz = gz.contiguous()
         st = self.store
         buckets = self.grad_buckets() if comm is not None else None
-        gpool = self._tensor("gpool", (B, self.feat_c))
-        ops.linear_bwd(self._pooled, st.p("linear.weight"), gz, gpool, st.g("linear.weight"), st.g("linear.bias"))
+        if gpooled is not None:      # after forward(head=False): the fused head kernel did the classifier's backward
+            gpool = gpooled
+        else:
+            gz = gz.contiguous()
+            gpool = self._tensor("gpool", (B, self.feat_c))
+            ops.linear_bwd(self._pooled, st.p("linear.weight"), gz, gpool, st.g("linear.weight"), st.g("linear.bias"))
         h, w = self._hw
         g = self.buf(f"g_out{self.feat_c}", B, h, w, self.feat_c)
         # plain avg-pool backward: identity BN with zero batch sums (the x>0 mask it applies is the
@@ -1009,13 +1044,25 @@ class ResNetEngine(_Engine):
             comm.finish(st.grad)
 
 
-def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None):
+def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None, fused_head=True):
     """One full training step (main.py:233-239): zero_grad, forward, SoftTreeSupLoss fwd+bwd (one fused
-    kernel), backward, [gradient all-reduce], SGD.  Returns the loss tensor (device scalar)."""
+    kernel -- with the classifier's forward and backward inside it when the criterion and the head's width allow,
+    fused_head=False keeps linear -> loss -> linear-backward as three launches), backward, [gradient all-reduce],
+    SGD.  Returns the loss tensor (device scalar)."""
     engine.zero_grad()
-    z = engine.forward(img, training=True)
-    loss, gz = criterion.loss_and_grad(z, targets)
-    engine.backward(gz, comm=comm)
+    names = getattr(engine, "classifier_names", None)
+    if (fused_head and names is not None and hasattr(criterion, "can_fuse_head")
+            and criterion.can_fuse_head(engine.num_classes)):
+        # classifier + rules + loss + their backward in ONE launch (nbdt_head_soft_tree_loss): logits stay on chip
+        pooled = engine.forward(img, training=True, head=False)
+        st = engine.store
+        loss, gpool, _ = criterion.head_loss_and_grad(pooled, st.p(names[0]), st.p(names[1]), targets,
+                                                      grad_weight=st.g(names[0]), grad_bias=st.g(names[1]))
+        engine.backward(None, comm=comm, gpooled=gpool)
+    else:
+        z = engine.forward(img, training=True)
+        loss, gz = criterion.loss_and_grad(z, targets)
+        engine.backward(gz, comm=comm)
     scale = 1.0 / comm.world_size if comm is not None else 1.0
     engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale)
     return loss

@@ -1,6 +1,8 @@
 """``generate_hierarchy`` -- reference nbdt/hierarchy.py:59-127 for the ``induced`` method (the one every
 shipped NBDT hierarchy uses).  ``wordnet`` needs the WordNet corpus (nltk, absent on the target image); ``random``
-ablation hierarchies and ``--extra`` augmentation are out of scope: all three raise."""
+ablation hierarchies and ``--extra`` augmentation are out of scope: GENERATING them
+raises here.  Hierarchy files of those kinds written by the reference still load (nbdt/tree.py), which is why
+nbdt.graph.generate_graph_fname keeps their naming scheme."""
 from nbdt.graph import build_induced_graph, get_graph_path_from_args, write_graph
 from nbdt.tree import get_wnids
 from nbdt.utils import dataset_to_default_path_wnids
@@ -19,7 +21,11 @@ def generate_hierarchy(dataset, method, seed=0, branching_factor=2, extra=0, no_
                             affinity=induced_affinity, branching_factor=branching_factor,
                             state_dict=model.state_dict() if model is not None else None)
     assert all(w in G.nodes for w in wnids)
-    # (the reference prunes single-successor nodes here; ward linkage only ever creates binary inner nodes)
+    # The reference prunes single-successor nodes here unless --no-prune (nbdt/hierarchy.py:96-98).  Agglomerative
+    # clustering merges exactly two clusters per step whatever the linkage, so an induced hierarchy never has such a
+    # node and pruning is the identity (no_prune only shows up in the file name) -- asserted rather than assumed:
+    inner = [n for n in G.nodes if n not in set(wnids)]
+    assert all(len(list(G.succ(n))) == 2 for n in inner), "induced hierarchy with a non-binary inner node"
     path = get_graph_path_from_args(dataset=dataset, method=method, seed=seed, branching_factor=branching_factor,
                                     extra=extra, no_prune=no_prune, fname=fname, path=path,
                                     multi_path=single_path, induced_linkage=induced_linkage,

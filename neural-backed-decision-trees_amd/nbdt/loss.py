@@ -158,6 +158,25 @@ class SoftTreeSupLoss(TreeSupLoss):
                                  grad_scale)
 
 
+    def can_fuse_head(self, num_classes):
+        """True when head_loss_and_grad() applies: plain cross entropy, a single-path hierarchy of at most 512 classes
+        and 512 child slots (the fused kernel's group of lanes per sample), matching the classifier's width."""
+        flat = self.tree.flat
+        return (_is_plain_cross_entropy(self.criterion) and flat.num_classes == num_classes
+                and flat.num_classes <= 512 and flat.num_slots <= 512 and flat.multi_path_node is None)
+
+    def head_loss_and_grad(self, pooled, weight, bias, targets, grad_weight=None, grad_bias=None, grad_scale=1.0,
+                           want_logits=False):
+        """Engine fast path with the classifier folded in (nbdt_head_soft_tree_loss, one launch): from the pooled
+        features [B, K] and the classifier's weight [C, K] / bias [C], returns (loss, dloss/dpooled * grad_scale,
+        logits or None) and ACCUMULATES the classifier's gradients into grad_weight / grad_bias.  Replaces
+        linear forward -> loss_and_grad -> linear backward; the logits stay on chip."""
+        xent_weight, tree_weight = self.current_weights()
+        handle = self.tree.device_handle(pooled.device.index)
+        return _C.head_soft_tree_loss(handle, pooled, weight, bias, targets, float(xent_weight), float(tree_weight),
+                                      grad_scale, gW=grad_weight, gb=grad_bias, want_logits=want_logits)
+
+
 class _FusedHardTreeLossFn(torch.autograd.Function):
     """HardTreeSupLoss and dloss/dz from one launch (csrc/rules.hip: hard_loss_kernel)."""
 

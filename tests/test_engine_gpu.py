@@ -84,10 +84,14 @@ def test_wrn_forward_backward_matches_bf16_emulating_oracle(pkg_dir):
     print("\n".join(report))
 
 
-def test_wrn_forward_backward_matches_fp32_oracle(pkg_dir):
-    """Against the pure fp32 oracle the bf16 storage shows up as ReLU-mask flips (an activation within
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_wrn_forward_backward_matches_fp32_oracle(deterministic, pkg_dir):
+    """(deterministic=True: the same comparison with nbdt_set_deterministic on -- per-block rows + ordered folds in
+    place of every fp32 atomic: only the summation order may differ from the default mode.)
+    Against the pure fp32 oracle the bf16 storage shows up as ReLU-mask flips (an activation within
     2^-9 of zero changes sign): unbiased, ~4% relative L2 per ReLU layer, so per-tensor gradients are
     compared by direction (cosine >= 0.97) and norm (within 5%), logits/loss tightly."""
+    from nbdt import ops
     ref, eng = _pair(10, 2, 10)
     otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-wrn28_10_cifar10", pkg_dir))
     crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
@@ -98,11 +102,16 @@ def test_wrn_forward_backward_matches_fp32_oracle(pkg_dir):
     ref.train()
     z_ref, loss_ref = _oracle_loss_backward(ref, otree, x, y)
 
-    eng.zero_grad()
-    z = eng.forward(x.to(DEV), training=True)
-    loss, gz = crit.loss_and_grad(z, y.to(DEV))
-    eng.backward(gz)
-    torch.cuda.synchronize()
+    ops.set_deterministic(deterministic)
+    try:
+        assert ops.is_deterministic() == deterministic
+        eng.zero_grad()
+        z = eng.forward(x.to(DEV), training=True)
+        loss, gz = crit.loss_and_grad(z, y.to(DEV))
+        eng.backward(gz)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(False)
 
     scale = z_ref.abs().max().item()
     assert (z.cpu() - z_ref).abs().max().item() < 3e-2 * scale, ((z.cpu() - z_ref).abs().max().item(), scale)
@@ -481,3 +490,134 @@ def test_ragged_batch_sizes_match_the_oracle(B, pkg_dir):
         if p.grad.norm().item() < 1e-6:
             continue
         assert _cos(grads[name], p.grad) > 0.93, (name, _cos(grads[name], p.grad))
+
+
+@pytest.fixture
+def deterministic_mode():
+    from nbdt import ops
+    ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(False)
+
+
+def _one_backward(eng, crit, x, y):
+    eng.zero_grad()
+    z = eng.forward(x, training=True)
+    loss, gz = crit.loss_and_grad(z, y)
+    eng.backward(gz)
+    torch.cuda.synchronize()
+    return z.clone(), loss.item(), eng.store.grad.clone()
+
+
+@pytest.mark.parametrize("B", [128, 512])
+def test_deterministic_mode_makes_the_schedules_bit_comparable(B, deterministic_mode):
+    """nbdt_set_deterministic: every cross-block reduction in a fixed order.  The reference's CPU path gives the same
+    bits on every run (stock ATen ops, nbdt/models/resnet.py:69-74); the default fast path does not (two runs of this
+    step differ by ~0.17 relative L2 of the gradient: fp32-atomic order moves 1-ulp bf16 roundings and ReLU masks),
+    which hides exactly the errors a schedule with two streams and shared buffers can make.  In deterministic mode:
+      (1) the same step twice on one engine: logits, loss and the whole flat gradient BIT-identical;
+      (2) the benched schedule -- CU-sharing split form, weight gradients on the second stream beside the CU-confined
+          BatchNorm passes, gradient buffers shared between units -- against the SAME launches (same CU counts and
+          budgets) issued on ONE stream with private buffers per unit: bit-identical, i.e. no launch of the two-stream
+          schedule reads a buffer before its producer finished or after a later unit overwrote it;
+      (3) the same for the default (fused-sums) schedule;
+      (4) the two schedules against each other (different summation orders in the BatchNorm-backward sums, so only
+          close): reported, and the loss identical (the forward pass is the same launches)."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (B,), generator=g).to(DEV)
+    results = {}
+    for schedule in ("cu-share-split", "default"):
+        def make(serial):
+            eng = E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=13)
+            if schedule == "default":
+                eng.set_cu_share(None)
+            else:
+                eng.set_cu_share(47.0, calibrate=False)
+            if serial:
+                eng.debug_keep = True              # private gradient buffers per unit
+                eng.debug_share_serial = True      # the sharing schedule's launches ...
+                eng.set_overlap(False)             # ... on one stream
+            return eng
+        two = make(False)
+        z1, l1, g1 = _one_backward(two, crit, x, y)
+        z2, l2, g2 = _one_backward(two, crit, x, y)
+        assert torch.equal(z1, z2) and l1 == l2, schedule
+        assert torch.equal(g1, g2), f"{schedule}: two runs differ, rel-L2 {_rel_l2(g2, g1):.3e}"
+        del two
+        one = make(True)
+        z3, l3, g3 = _one_backward(one, crit, x, y)
+        assert torch.equal(z1, z3) and l1 == l3, schedule
+        assert torch.equal(g1, g3), f"{schedule}: two streams + shared buffers differ from one stream + private " \
+                                    f"buffers, rel-L2 {_rel_l2(g1, g3):.3e}"
+        results[schedule] = (l1, g1)
+        del one
+    (la, ga), (lb, gb) = results["cu-share-split"], results["default"]
+    rel = _rel_l2(ga, gb)
+    print(f"B={B}: split vs default schedule, deterministic mode: loss {la:.6f} / {lb:.6f}, gradient rel-L2 {rel:.3e}")
+    # measured 4.3e-3 (B=512) / 5.4e-3 (B=128): the two schedules sum the BatchNorm-backward terms in different orders
+    # (per-tile partials from the data gradient's epilogue vs per-CU rows), 1-ulp differences in dsum move bf16
+    # roundings of gx -- against 0.17 between two runs of ONE schedule without deterministic mode
+    assert la == lb and rel < 1.5e-2, rel
+
+
+def test_deterministic_mode_resnet18_and_training_steps(deterministic_mode):
+    """Two independent engines with the same seed, four full training steps each (forward, loss, backward, SGD):
+    parameters, momentum buffers and running statistics stay bit-identical in deterministic mode -- for the ResNet18
+    engine (BatchNorm sums through nbdt_bn_stats / nbdt_bn_bwd_reduce, strided and 1x1 weight gradients) and for
+    WRN-28-10 at a batch (96) whose launches mix the 8-wave and 4-wave kernels."""
+    for make, classes, hierarchy, B in (
+            (lambda: E.ResNetEngine(num_classes=10, device=DEV, seed=3), 10, "induced-ResNet18", 64),
+            (lambda: E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=3), 10,
+             "induced-wrn28_10_cifar10", 96)):
+        crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy=hierarchy)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 3, 32, 32, generator=g).to(DEV)
+        y = torch.randint(0, classes, (B,), generator=g).to(DEV)
+        runs = []
+        for _ in range(2):
+            eng = make()
+            if hasattr(eng, "units"):
+                eng.set_cu_share(47.0, calibrate=False)
+            losses = [E.train_step(eng, crit, x, y, lr=0.05).item() for _ in range(4)]
+            torch.cuda.synchronize()
+            runs.append((losses, eng.store.flat.clone(), eng.store.mom.clone(),
+                         torch.cat([b.running_var for b in eng.bns]).clone()))
+        assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+        for a, b in zip(runs[0][1:], runs[1][1:]):
+            assert torch.equal(a, b)
+        assert runs[0][0][-1] < runs[0][0][0]
+
+
+def test_fused_head_step_equals_the_three_launch_step(deterministic_mode):
+    """train_step(fused_head=True) -- classifier forward, rules, SoftTreeSupLoss and the classifier's backward in one
+    launch (nbdt_head_soft_tree_loss) -- against fused_head=False (linear -> loss -> linear backward).  Below 64
+    classes the head's logits and dL/dpooled are bit-identical to the unfused launches', so in deterministic mode the
+    WHOLE backbone gradient must be bit-identical too; only the classifier's own dW / db may differ in summation
+    order.  WRN-28-10 at 64 images and ResNet18."""
+    for make, names, hierarchy in (
+            (lambda: E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=DEV, seed=6),
+             ("output.weight", "output.bias"), "induced-wrn28_10_cifar10"),
+            (lambda: E.ResNetEngine(num_classes=10, device=DEV, seed=6), ("linear.weight", "linear.bias"),
+             "induced-ResNet18")):
+        crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy=hierarchy)
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(64, 3, 32, 32, generator=g).to(DEV)
+        y = torch.randint(0, 10, (64,), generator=g).to(DEV)
+        out = {}
+        for fused in (True, False):
+            eng = make()
+            if hasattr(eng, "units"):
+                eng.set_cu_share(None)
+            loss = E.train_step(eng, crit, x, y, lr=0.0, momentum=0.0, weight_decay=0.0, fused_head=fused)
+            torch.cuda.synchronize()
+            out[fused] = (loss.item(), {k: v.clone() for k, v in eng.named_params("grad").items()})
+        assert out[True][0] == out[False][0]
+        for name, gf in out[True][1].items():
+            gu = out[False][1][name]
+            if name in names:
+                assert (gf - gu).abs().max().item() < 2e-5 * gu.abs().max().item() + 1e-9, name
+            else:
+                assert torch.equal(gf, gu), name

@@ -353,3 +353,80 @@ def test_shape_and_target_contracts(pkg_dir):
     assert abs(hard_loss.item() - soft_loss.item()) < 1e-5 * abs(hard_loss.item())
     with pytest.raises(_C.NBDTHipError, match="class-index"):
         crit.loss_and_grad(z, onehot)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# N1: classifier head + rules + SoftTreeSupLoss, forward and backward, in one launch (nbdt_head_soft_tree_loss)
+
+@pytest.mark.parametrize("tag,K,B", [("cifar10_wrn", 640, 512), ("cifar10_r18", 512, 7), ("cifar100_wrn", 640, 256),
+                                     ("tiny_r18", 512, 130), ("cifar100_wordnet", 640, 33)])
+def test_fused_head_equals_linear_then_loss_then_linear_backward(tag, K, B, golden_dir, pkg_dir):
+    """The fused head against the three launches it replaces (nbdt_linear_fwd -> nbdt_soft_tree_loss ->
+    nbdt_linear_bwd; reference nn.Linear + nbdt/loss.py:191-203, 264-266) on the same features / weights, and against
+    the numpy oracle on the logits it reports:
+      * logits: bit-identical to nbdt_linear_fwd for heads below 64 classes (same one-wave-per-output arithmetic;
+        wider heads take nbdt_linear_fwd's tiled GEMM: 1e-5 of the logit scale);
+      * loss 1e-6 rel and dL/dz (through dL/dpooled, dL/dW, dL/db) against the unfused launches;
+      * loss / dL/dz of the numpy oracle on the reported logits: 1e-5 rel / 1e-6 abs, hard decisions bit-exact;
+      * ragged batches (7, 33, 130: the last block holds fewer samples than it has groups)."""
+    from nbdt import ops
+    _, tree, otree, ds, h = _case(tag, golden_dir, pkg_dir)
+    handle = tree.device_handle(0)
+    C = tree.flat.num_classes
+    g = torch.Generator().manual_seed(B + K)
+    pooled = torch.rand(B, K, generator=g).mul_(2.0).to(DEV)             # post-ReLU averages: non-negative
+    W = torch.randn(C, K, generator=g).mul_(K ** -0.5).to(DEV)
+    bias = torch.randn(C, generator=g).mul_(0.1).to(DEV)
+    y = torch.randint(0, C, (B,), generator=g).to(DEV)
+    for wx, wt in ((1.0, 1.0), (0.5, 10.0)):
+        gW, gb = torch.zeros_like(W), torch.zeros_like(bias)
+        loss, gp, z = _C.head_soft_tree_loss(handle, pooled, W, bias, y, wx, wt, gW=gW, gb=gb, want_logits=True)
+        # --- the unfused sequence
+        z_ref = torch.empty(B, C, device=DEV)
+        ops.linear_fwd(pooled, W, bias, z_ref)
+        loss_ref, gz_ref = _C.soft_tree_loss(handle, z_ref, y, wx, wt)
+        gp_ref, gW_ref, gb_ref = torch.empty_like(pooled), torch.zeros_like(W), torch.zeros_like(bias)
+        ops.linear_bwd(pooled, W, gz_ref, gp_ref, gW_ref, gb_ref)
+        scale = z_ref.abs().max().item()
+        if C < 64:
+            assert torch.equal(z, z_ref)
+            assert torch.equal(gp, gp_ref)          # same gz, same ascending-class fused multiply-add chain
+            assert loss.item() == loss_ref.item()
+        else:
+            assert (z - z_ref).abs().max().item() < 1e-5 * scale
+            assert (gp - gp_ref).abs().max().item() < 1e-5 * gp_ref.abs().max().item() + 1e-9
+            assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+        assert (gW - gW_ref).abs().max().item() < 2e-5 * gW_ref.abs().max().item() + 1e-9
+        assert (gb - gb_ref).abs().max().item() < 2e-5 * gb_ref.abs().max().item() + 1e-9
+        # --- the oracle on the logits the head reports
+        zn = z.cpu().numpy()
+        lo, dzo = O.soft_tree_sup_loss(otree, zn, y.cpu().numpy(), wx, wt)
+        assert abs(loss.item() - lo) < 1e-5 * abs(lo)
+        gp_oracle = torch.from_numpy(dzo).to(DEV) @ W                       # dL/dpooled = dL/dz W
+        assert (gp - gp_oracle).abs().max().item() < 1e-5 * gp_oracle.abs().max().item() + 1e-8
+        pred = _C.hard_forward(handle, z, want_onehot=False)[0].cpu().numpy()
+        assert np.array_equal(pred, O.hard_forward(otree, zn))
+    # accumulate semantics and the optional outputs
+    gW2 = gW.clone()
+    loss2, gp2, z2 = _C.head_soft_tree_loss(handle, pooled, W, bias, y, 0.5, 10.0, gW=gW2, want_gpooled=False)
+    assert gp2 is None and z2 is None and loss2.item() == loss.item()
+    assert (gW2 - 2 * gW).abs().max().item() < 1e-5 * gW.abs().max().item() + 1e-9
+
+
+def test_fused_head_refuses_wide_classifiers_and_bad_shapes(golden_dir, pkg_dir):
+    _, tree, _, _, _ = _case("imagenet_eff", golden_dir, pkg_dir)          # 1000 classes: the unfused path's job
+    handle = tree.device_handle(0)
+    pooled, W = torch.rand(4, 1280, device=DEV), torch.randn(1000, 1280, device=DEV)
+    y = torch.zeros(4, dtype=torch.long, device=DEV)
+    with pytest.raises(_C.NBDTHipError, match="too wide"):
+        _C.head_soft_tree_loss(handle, pooled, W, None, y, 1.0, 1.0)
+    crit = SoftTreeSupLoss(dataset="Imagenet1000", criterion=nn.CrossEntropyLoss(), hierarchy="induced-efficientnet_b7b")
+    assert not crit.can_fuse_head(1000)
+    _, tree10, _, _, _ = _case("cifar10_wrn", golden_dir, pkg_dir)
+    with pytest.raises(_C.NBDTHipError, match="classifier weight"):
+        _C.head_soft_tree_loss(tree10.device_handle(0), torch.rand(4, 640, device=DEV), torch.randn(12, 640, device=DEV),
+                               None, y, 1.0, 1.0)
+    crit10 = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-wrn28_10_cifar10")
+    assert crit10.can_fuse_head(10) and not crit10.can_fuse_head(100)
+    assert not SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(label_smoothing=0.1),
+                               hierarchy="induced-wrn28_10_cifar10").can_fuse_head(10)

@@ -7,11 +7,12 @@ batches (BASELINE.json `metric`, configs[1]: batch 512 per MI355X, fused rules/l
    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...,
    one rank per GPU over RCCL; launched that way by a driver it just reads RANK/LOCAL_RANK/WORLD_SIZE.)
 
-A "step" = zero_grad -> backbone forward -> SoftTreeSupLoss forward+backward (one fused kernel) ->
-backbone backward -> [RCCL all-reduce of gradients, overlapped] -> SGD(momentum .9, wd 5e-4) on one
-batch already resident in HBM.  In backward the HBM-bound BatchNorm passes run on ~50 CUs BESIDE the MFMA-bound weight
-gradients on the other ~200 (engine.set_cu_share; `cu_share` in the JSON line is the one-pair calibration the first
-warm-up step made; --no-cu-share restores the order without it).  Weak scaling: 512 images per GPU.  Prints ONE JSON line on rank 0.
+A "step" = nbdt.engine.train_step, the engine's default schedule: zero_grad -> backbone forward to the pooled features
+-> classifier + rules + SoftTreeSupLoss forward AND backward in one launch (nbdt_head_soft_tree_loss) -> backbone
+backward -> [RCCL all-reduce of gradients, overlapped] -> SGD(momentum .9, wd 5e-4) on one batch already resident in
+HBM.  In backward the HBM-bound BatchNorm passes run on ~100 CUs BESIDE the MFMA-bound weight gradients on the other
+~160 (engine.set_cu_share, on by default; `cu_share` in the JSON line is the calibration made before the first
+backward; --no-cu-share restores the order without it).  Weak scaling: 512 images per GPU.  Prints ONE JSON line on rank 0.
 
 roofline: the dominant kernel is conv_igemm (forward + data-gradient implicit GEMMs; 2/3 of the
 step's flops).  achieved = algorithmic flops of its launches / their HIP-event durations, measured

@@ -373,10 +373,10 @@ int nbdt_linear_bwd(const float* x, const float* w, const float* gz, int32_t B, 
                     float* gx, float* gw, float* gb, void* stream);
 /* optim.SGD(momentum, weight_decay) over a flat fp32 buffer (main.py:207):
  * g = grad_scale*g + wd*p; buf = mom*buf + g; p -= lr*buf; optionally refreshes the bf16 copy the
- * conv kernels read (same element order as p) in the same pass */
-int nbdt_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
-                  float weight_decay, float grad_scale, void* p_bf16 /* nullable: bf16 copy of p */,
-                  void* stream);
+ * conv kernels read (same element order as p) in the same pass; zero_grad != 0 also zeroes g (optimizer.zero_grad()
+ * of the next step, main.py:235, folded into the same pass) */
+int nbdt_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float momentum,
+                  float weight_decay, float grad_scale, void* p_bf16, int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

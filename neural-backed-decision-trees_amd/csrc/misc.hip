@@ -362,9 +362,11 @@ extern "C" int nbdt_linear_bwd(const float* x, const float* w, const float* gz, 
 }
 
 // ------------------------------------------------------------------------------------------ sgd
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+// zero_g: also leave the gradient buffer zeroed for the next step's accumulating weight-gradient kernels (a separate
+// 146 MB fill took 108 us per WRN-28-10 step; here it is one more store stream of a pass that is HBM-bound anyway)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ buf, long long n, float lr, float momentum,
-                                                  float wd, float gscale, bf16_t* __restrict__ pb) {
+                                                  float wd, float gscale, bf16_t* __restrict__ pb, int zero_g) {
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 pv = ((const float4*)p)[i];
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     pv.x -= lr * bv.x; pv.y -= lr * bv.y; pv.z -= lr * bv.z; pv.w -= lr * bv.w;
     ((float4*)buf)[i] = bv;
     ((float4*)p)[i] = pv;
+    if (zero_g) ((float4*)g)[i] = float4{0.f, 0.f, 0.f, 0.f};
     if (pb) {
       uint2 o;
       o.x = pack_bf16x2(pv.x, pv.y);
@@ -390,12 +393,13 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     const float b = momentum * buf[i] + (gscale * g[i] + wd * p[i]);
     buf[i] = b;
     p[i] -= lr * b;
+    if (zero_g) g[i] = 0.f;
     if (pb) pb[i] = f32_to_bf16(p[i]);
   }
 }
 
-extern "C" int nbdt_sgd_step(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
-                             float weight_decay, float grad_scale, void* p_bf16, void* stream) {
+extern "C" int nbdt_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float momentum,
+                             float weight_decay, float grad_scale, void* p_bf16, int32_t zero_grad, void* stream) {
   NBDT_REQUIRE(p && g && buf && n > 0, "bad sgd arguments");
   NBDT_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0,
                "flat buffers must be 16-byte aligned");
@@ -404,7 +408,7 @@ extern "C" int nbdt_sgd_step(float* p, const float* g, float* buf, int64_t n, fl
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, (long long)n, lr,
-                     momentum, weight_decay, grad_scale, (bf16_t*)p_bf16);
+                     momentum, weight_decay, grad_scale, (bf16_t*)p_bf16, zero_grad ? 1 : 0);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

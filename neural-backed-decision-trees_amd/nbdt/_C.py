@@ -119,7 +119,7 @@ SIGNATURES = {
     "nbdt_dropout_bwd": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "nbdt_linear_fwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_linear_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
-    "nbdt_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
+    "nbdt_sgd_step": (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, c_int32, _P]),
 }
 
 

@@ -533,15 +533,20 @@ class _Engine:
             if self._wt_n:
                 ops.weight_tile_batched(self._wd_flat, self._wt_dtable, self._wt_n, self._wt_dtotal, self._wt_dgrad)
 
-    def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
-        """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights."""
+    def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, zero_grad=False):
+        """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights.
+        zero_grad: the same pass leaves the gradient buffer zeroed, and the next zero_grad() is then free (the separate
+        146 MB fill took 108 us per WRN-28-10 step; train_step asks for it)."""
         self.join_side_stream()
         s = self.store
-        ops.sgd_step(s.flat, s.grad, s.mom, lr, momentum, weight_decay, grad_scale, s.bf16)
+        ops.sgd_step(s.flat, s.grad, s.mom, lr, momentum, weight_decay, grad_scale, s.bf16, zero_grad=zero_grad)
+        self._grad_is_zero = bool(zero_grad)
         self.refresh_derived_weights()
 
     def zero_grad(self):
-        self.store.zero_grad()
+        if not getattr(self, "_grad_is_zero", False):
+            self.store.zero_grad()
+        self._grad_is_zero = False       # whatever runs next may accumulate into it
 
     # ---- logical (reference-named) parameter / buffer views for state_dict compatibility
     def extra_param_views(self, buf):
@@ -717,6 +722,7 @@ class WRNEngine(_Engine):
         forward(head=False), given gpooled = dloss/dpooled [B, feat_c] (the fused head kernel already accumulated the
         classifier's gradients).  With a GradComm, each stage's gradient bucket is all-reduced as soon as it is
         complete."""
+        self._grad_is_zero = False   # this call accumulates into the gradient buffer
         B = self._B
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         if self._cu_share is not None and not self._share_calibrated:
@@ -976,6 +982,7 @@ class ResNetEngine(_Engine):
         return z
 
     def backward(self, gz, comm=None, gpooled=None):
+        self._grad_is_zero = False   # this call accumulates into the gradient buffer
         B = self._B
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         st = self.store
@@ -1064,7 +1071,7 @@ def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5
         loss, gz = criterion.loss_and_grad(z, targets)
         engine.backward(gz, comm=comm)
     scale = 1.0 / comm.world_size if comm is not None else 1.0
-    engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale)
+    engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale, zero_grad=True)
     return loss
 
 

@@ -260,6 +260,7 @@ class EfficientNetEngine(_Engine):
 
     # ------------------------------------------------------------------ backward
     def backward(self, gz, comm=None):
+        self._grad_is_zero = False   # this call accumulates into the gradient buffer
         B = self._B
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         st = self.store

@@ -431,9 +431,10 @@ def linear_bwd(x, w, gz, gx, gw, gb):
                                 stream_ptr(x.device)))
 
 
-def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, p_bf16=None):
+def sgd_step(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, p_bf16=None, zero_grad=False):
+    """zero_grad: the same pass leaves g zeroed (the next step's zero_grad())."""
     check(lib().nbdt_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, momentum, weight_decay, grad_scale,
-                              ptr(p_bf16), stream_ptr(p.device)))
+                              ptr(p_bf16), 1 if zero_grad else 0, stream_ptr(p.device)))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -621,3 +621,35 @@ def test_fused_head_step_equals_the_three_launch_step(deterministic_mode):
                 assert (gf - gu).abs().max().item() < 2e-5 * gu.abs().max().item() + 1e-9, name
             else:
                 assert torch.equal(gf, gu), name
+
+
+def test_sgd_kernel_zeroes_the_gradient_for_the_next_step(deterministic_mode):
+    """train_step asks nbdt_sgd_step to leave the gradient buffer zeroed (one more store stream of an HBM-bound pass
+    instead of a separate 146 MB fill per step) and the next zero_grad() is then free.  Same parameters, bit for bit, as
+    the explicit sequence zero_grad -> forward -> loss -> backward -> sgd_step(zero_grad=False); an accumulating
+    backward() in between re-arms the real fill."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(32, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (32,), generator=g).to(DEV)
+    a = E.WRNEngine(num_classes=10, blocks=10, width_factor=2, device=DEV, seed=1)
+    b = E.WRNEngine(num_classes=10, blocks=10, width_factor=2, device=DEV, seed=1)
+    for _ in range(3):
+        E.train_step(a, crit, x, y, lr=0.05, fused_head=False)     # (b below runs the three-launch head too)
+        assert a._grad_is_zero and float(a.store.grad.abs().max()) == 0.0
+        b.zero_grad()
+        z = b.forward(x, training=True)
+        _, gz = crit.loss_and_grad(z, y)
+        b.backward(gz)
+        assert not b._grad_is_zero
+        b.sgd_step(0.05)
+        assert float(b.store.grad.abs().max()) > 0.0
+    torch.cuda.synchronize()
+    assert torch.equal(a.store.flat, b.store.flat) and torch.equal(a.store.mom, b.store.mom)
+    # a backward outside train_step accumulates; the next zero_grad() must really clear it
+    z = a.forward(x, training=True)
+    _, gz = crit.loss_and_grad(z, y)
+    a.backward(gz)
+    assert float(a.store.grad.abs().max()) > 0.0
+    a.zero_grad()
+    assert float(a.store.grad.abs().max()) == 0.0

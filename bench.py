@@ -296,8 +296,9 @@ def main():
         k = summ.get("conv_igemm")
         if k:
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "conv_igemm: conv3x3_pp_kernel (44 of 60 launches, 96 % of the flops) / "
-                                         "conv_igemm_dma_kernel (forward + data-gradient implicit GEMM, 2/3 of the step's flops)",
+                               "kernel": "conv_igemm: conv3x3_pp_kernel (44 launches, 96 % of the flops) / "
+                                         "conv_igemm_dma[_multi]_kernel (strided, 1x1, parity-class launches) -- every "
+                                         "forward + data-gradient implicit GEMM, 2/3 of the step's flops",
                                "achieved": round(k["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "traffic_source": traffic_src,

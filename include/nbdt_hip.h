@@ -181,6 +181,12 @@ typedef struct nbdt_conv_desc {
 int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                     const void* residual, void* stream);
 
+/* Up to four nbdt_conv_igemm launches over the SAME operands in one grid (no residual, no statistics; `accumulate`
+ * must agree): the output-parity classes of a strided 3x3 data gradient write disjoint pixels, and each alone fills a
+ * quarter of the chip at 512 images.  Same arithmetic per descriptor as nbdt_conv_igemm (bit-identical outputs).
+ * Replaces the conv-transpose autograd of a strided nn.Conv2d (pytorchcv PreResUnit's first conv of a stage). */
+int nbdt_conv_igemm_multi(const nbdt_conv_desc* descs, int32_t n, const void* in, const void* w, void* out,
+                          void* stream);
 /* same launch, and the epilogue also writes the per-channel sum / sum of squares of the (bf16) output
  * of every 256-pixel tile to bn_partials[ceil(M/256)][2][cout] (plain stores, fully overwritten) -- the
  * statistics the following BatchNorm needs, so nbdt_bn_finalize can replace nbdt_bn_stats (no second

@@ -156,6 +156,7 @@ struct BnBwdArgs {   // epilogue extras: the BatchNorm whose input gradient a dg
 };
 int conv_igemm_dma(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* res,
                    float* stats, const BnBwdArgs* bn, int M, hipStream_t st);
+int conv_igemm_dma_multi(const nbdt_conv_desc* descs, int n, const void* in, const void* w, void* out, hipStream_t st);
 
 // conv_halo.hip: 3x3 stride-1 kernel with an LDS-resident halo tile (preferred when applicable)
 struct HaloGeom {

@@ -27,19 +27,13 @@
 
 using namespace nbdt;
 
+static int check_desc(const nbdt_conv_desc* d);
+
 static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* w, void* out, const void* residual,
                            float* bn_scratch, void* stream, const nbdt::BnBwdArgs* bn = nullptr) {
   NBDT_REQUIRE(d && in && w && out, "null argument");
-  NBDT_REQUIRE(d->cin > 0 && d->cin % 32 == 0, "cin must be a multiple of 32");
-  NBDT_REQUIRE(d->cout > 0 && d->cout % 32 == 0, "cout must be a multiple of 32");
-  NBDT_REQUIRE(d->ntaps >= 1 && d->ntaps <= 9 && d->w_ntaps >= 1, "bad tap table");
-  for (int t = 0; t < d->ntaps; ++t) NBDT_REQUIRE(d->w_tap[t] >= 0 && d->w_tap[t] < d->w_ntaps, "bad w_tap");
-  NBDT_REQUIRE(d->B > 0 && d->gh > 0 && d->gw > 0, "empty pixel grid");
-  NBDT_REQUIRE((d->in_base % 8) == 0 && (d->in_ws % 8) == 0 && (d->in_hs % 8) == 0 && (d->in_bs % 8) == 0,
-               "input pixel offsets must be 16-byte aligned");
-  NBDT_REQUIRE((d->out_base % 4) == 0 && (d->out_ws % 4) == 0 && (d->out_hs % 4) == 0 && (d->out_bs % 4) == 0,
-               "output pixel offsets must be 8-byte aligned");
-  for (int t = 0; t < d->ntaps; ++t) NBDT_REQUIRE(d->tap_off[t] % 8 == 0, "tap offsets must be 16-byte aligned");
+  int rc = check_desc(d);
+  if (rc) return rc;
   const void* res = d->accumulate ? (const void*)out : residual;
   NBDT_REQUIRE(!(d->accumulate && residual), "accumulate and residual are exclusive");
   const int64_t M64 = (int64_t)d->B * d->gh * d->gw;
@@ -55,7 +49,37 @@ static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* 
   return nbdt::conv_igemm_dma(d, in, w, out, res, bn_scratch, bn, M, st);
 }
 
+static int check_desc(const nbdt_conv_desc* d) {
+  NBDT_REQUIRE(d->cin > 0 && d->cin % 32 == 0, "cin must be a multiple of 32");
+  NBDT_REQUIRE(d->cout > 0 && d->cout % 32 == 0, "cout must be a multiple of 32");
+  NBDT_REQUIRE(d->ntaps >= 1 && d->ntaps <= 9 && d->w_ntaps >= 1, "bad tap table");
+  for (int t = 0; t < d->ntaps; ++t) NBDT_REQUIRE(d->w_tap[t] >= 0 && d->w_tap[t] < d->w_ntaps, "bad w_tap");
+  NBDT_REQUIRE(d->B > 0 && d->gh > 0 && d->gw > 0, "empty pixel grid");
+  NBDT_REQUIRE((d->in_base % 8) == 0 && (d->in_ws % 8) == 0 && (d->in_hs % 8) == 0 && (d->in_bs % 8) == 0,
+               "input pixel offsets must be 16-byte aligned");
+  NBDT_REQUIRE((d->out_base % 4) == 0 && (d->out_ws % 4) == 0 && (d->out_hs % 4) == 0 && (d->out_bs % 4) == 0,
+               "output pixel offsets must be 8-byte aligned");
+  for (int t = 0; t < d->ntaps; ++t) NBDT_REQUIRE(d->tap_off[t] % 8 == 0, "tap offsets must be 16-byte aligned");
+  NBDT_REQUIRE((int64_t)d->B * d->gh * d->gw < (1ll << 31), "pixel grid too large");
+  return NBDT_OK;
+}
+
 extern "C" const char* nbdt_debug_last_igemm(void) { return nbdt::g_last_igemm; }
+
+extern "C" int nbdt_conv_igemm_multi(const nbdt_conv_desc* descs, int32_t n, const void* in, const void* w, void* out,
+                                     void* stream) {
+  NBDT_REQUIRE(descs && in && w && out, "null argument");
+  NBDT_REQUIRE(n >= 1 && n <= 4, "1 to 4 descriptors per launch");
+  for (int c = 0; c < n; ++c) {
+    int rc = check_desc(descs + c);
+    if (rc) return rc;
+    NBDT_REQUIRE(descs[c].cout == descs[0].cout && descs[c].cin == descs[0].cin &&
+                 descs[c].accumulate == descs[0].accumulate && descs[c].w_ntaps == descs[0].w_ntaps,
+                 "the descriptors of one launch share channels, weight layout and accumulate");
+  }
+  nbdt::g_last_igemm = "conv_igemm_dma_multi_kernel";
+  return nbdt::conv_igemm_dma_multi(descs, n, in, w, out, (hipStream_t)stream);
+}
 
 extern "C" int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                                const void* residual, void* stream) {

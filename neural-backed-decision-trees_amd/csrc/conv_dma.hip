@@ -31,7 +31,7 @@ constexpr int min_w_dma(int w_instr) {
 }
 
 template <int NT, bool HAS_RES, int STATS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaParams p) {
+__device__ __forceinline__ void conv_igemm_dma_body(const nbdt::ConvDmaParams& p, const int bid) {
   constexpr int BN = 32 * NT;
   constexpr int A_BYTES = BM * BK * 2;  // 16 KiB
   constexpr int W_BYTES = BN * BK * 2;
@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
   constexpr int MINPW = A_INSTR / 4 + min_w_dma(W_INSTR);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int bid = blockIdx.x;
   const int item = (bid & 7) * p.per_xcd + (bid >> 3);
   if (item >= p.m_blocks * p.n_blocks) return;
   const int m_blk = item / p.n_blocks;
@@ -166,6 +165,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaPar
   conv_epilogue<NT, HAS_RES, STATS>(acc, p, epi_lds_packed<NT, 4>(smem, wave), m0, n0, m_blk, wave, lane, tid);
 }
 
+template <int NT, bool HAS_RES, int STATS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(nbdt::ConvDmaParams p) {
+  conv_igemm_dma_body<NT, HAS_RES, STATS>(p, blockIdx.x);
+}
+
+// Several launches of the kernel above in ONE grid: the four output-parity classes of a strided 3x3 data gradient
+// (1 + 2 + 2 + 4 taps, disjoint output pixels, the same operands) are 128 pixel tiles each at 512 images -- a quarter
+// of the chip per launch when they run one after the other.  Block b belongs to class c with first[c] <= b <
+// first[c + 1] and runs that class's descriptor with the class-local block index (every first[] is a multiple of 8, so
+// the XCD-contiguous item walk holds per class).
+namespace nbdt {
+struct ConvDmaMulti {
+  ConvDmaParams p[4];
+  int first[5];
+};
+}  // namespace nbdt
+template <int NT, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_multi_kernel(nbdt::ConvDmaMulti mp) {
+  const int b = blockIdx.x;
+  const int c = b >= mp.first[2] ? (b >= mp.first[3] ? 3 : 2) : (b >= mp.first[1] ? 1 : 0);
+  conv_igemm_dma_body<NT, HAS_RES, 0>(mp.p[c], b - mp.first[c]);
+}
+
 namespace nbdt {
 
 template <int NT>
@@ -195,6 +217,60 @@ static int launch_dma(ConvDmaParams& p, hipStream_t st) {
 #undef NBDT_GO
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
+}
+
+template <int NT>
+static int launch_dma_multi(ConvDmaMulti& mp, int n, bool accumulate, hipStream_t st) {
+  constexpr int BN = 32 * NT;
+  int blocks = 0;
+  for (int c = 0; c < 4; ++c) {
+    mp.first[c] = blocks;
+    if (c >= n) continue;
+    ConvDmaParams& p = mp.p[c];
+    p.n_blocks = p.d.cout / BN;
+    p.m_blocks = (p.M + BM - 1) / BM;
+    p.per_xcd = (p.m_blocks * p.n_blocks + 7) / 8;
+    blocks += p.per_xcd * 8;
+  }
+  mp.first[4] = blocks;
+  for (int c = n; c < 4; ++c) { mp.p[c] = mp.p[0]; mp.first[c] = blocks; }     // (never selected)
+  const size_t shmem = (size_t)NSTAGE * ((BM * BK * 2) + (BN * BK * 2));
+  static DeviceAttr site;     // one per NT instantiation
+  if (site.need(shmem)) {
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_multi_kernel<NT, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_multi_kernel<NT, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    site.done(shmem);
+  }
+  if (accumulate) hipLaunchKernelGGL((conv_igemm_dma_multi_kernel<NT, true>), dim3(blocks), dim3(256), shmem, st, mp);
+  else hipLaunchKernelGGL((conv_igemm_dma_multi_kernel<NT, false>), dim3(blocks), dim3(256), shmem, st, mp);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+// called by nbdt_conv_igemm_multi (conv.hip) after argument validation: n <= 4 descriptors over the same operands
+int conv_igemm_dma_multi(const nbdt_conv_desc* descs, int n, const void* in, const void* w, void* out,
+                         hipStream_t st) {
+  static thread_local ConvDmaMulti mp;      // (1.7 KB: kept off the stack of the ctypes caller)
+  for (int c = 0; c < n; ++c) {
+    ConvDmaParams& p = mp.p[c];
+    p = ConvDmaParams{};
+    p.d = descs[c];
+    p.in = (const bf16_t*)in;
+    p.w = (const bf16_t*)w;
+    p.out = (bf16_t*)out;
+    p.res = descs[c].accumulate ? (const bf16_t*)out : nullptr;
+    p.M = descs[c].B * descs[c].gh * descs[c].gw;
+    p.deterministic = deterministic() ? 1 : 0;
+  }
+  const bool acc = descs[0].accumulate != 0;
+  const int nt32 = descs[0].cout / 32;
+  if (nt32 % 5 == 0) return launch_dma_multi<5>(mp, n, acc, st);
+  if (nt32 % 4 == 0) return launch_dma_multi<4>(mp, n, acc, st);
+  if (nt32 % 3 == 0) return launch_dma_multi<3>(mp, n, acc, st);
+  if (nt32 % 2 == 0) return launch_dma_multi<2>(mp, n, acc, st);
+  return launch_dma_multi<1>(mp, n, acc, st);
 }
 
 // called by nbdt_conv_igemm (conv.hip) after argument validation

@@ -80,6 +80,7 @@ SIGNATURES = {
     "nbdt_hard_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "nbdt_node_outputs": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "nbdt_conv_igemm_multi": (c_int, [_P, c_int32, _P, _P, _P, _P]),
     "nbdt_conv_igemm_stats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "nbdt_bn_finalize": (c_int, [c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

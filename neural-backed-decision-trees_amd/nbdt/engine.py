@@ -99,6 +99,7 @@ class Conv:
         store.add(name, (self.cout, self.taps, self.cin), init)
         self._plans = {}
         self.wd = None
+        self.merge_parity_classes = True   # (A/B: False launches the parity classes of a strided data gradient one by one)
 
     def logical(self, buf):
         """[cout_real, cin_real, k, k] view (OIHW semantics, channels_last memory) of a flat buffer."""
@@ -151,6 +152,9 @@ class Conv:
         if bn is not None:
             assert len(descs) == 1 and not accumulate
             ops.conv_igemm_bnbwd(descs[0], gout, self.wd, gin, bn_x, bn.mean, bn.rstd, bn.gamma, bn.beta, partials)
+            return
+        if len(descs) > 1 and self.merge_parity_classes:      # strided 3x3: four parity classes, one grid
+            ops.conv_igemm_multi(descs, gout, self.wd, gin)
             return
         for d in descs:
             ops.conv_igemm(d, gout, self.wd, gin)

@@ -216,6 +216,19 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
         ev[1].record()
 
 
+def conv_igemm_multi(descs, inp, w_bf16, out):
+    """The launches of `descs` (<= 4, same operands: the parity classes of a strided 3x3 data gradient) in one grid."""
+    arr = (ConvDesc * len(descs))(*descs)
+    ev = None
+    if _timer is not None and _timer.wants("conv_igemm"):
+        flops = sum(2.0 * d.B * d.gh * d.gw * d.cout * d.ntaps * d.cin for d in descs)
+        ev = _timer.bracket("conv_igemm", flops, inp.device)
+        ev[0].record()
+    check(lib().nbdt_conv_igemm_multi(arr, len(descs), ptr(inp), ptr(w_bf16), ptr(out), stream_ptr(inp.device)))
+    if ev is not None:
+        ev[1].record()
+
+
 def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, partials):
     """dgrad launch that also produces the BatchNorm-backward sums of (out, bn_x) as per-tile partials."""
     ev = None

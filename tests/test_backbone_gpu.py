@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from nbdt import ops  # noqa: E402
+from nbdt import _C, ops  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -775,3 +775,34 @@ def test_weight_gradient_kernel_variants(B, H, W, cin, cout):
         np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), **tol)
         ops.conv_wgrad(d, xp, gp, dw)
         np.testing.assert_allclose(dw.cpu().numpy(), 2 * gw_ref.numpy(), rtol=2e-3, atol=2 * tol["atol"])
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 160, 320), (6, 16, 16, 320, 640), (64, 32, 32, 160, 320),
+                                            (5, 8, 8, 64, 128)])
+def test_parity_classes_of_a_strided_data_gradient_in_one_launch(B, H, W, cin, cout):
+    """nbdt_conv_igemm_multi: the four output-parity classes of a strided 3x3 data gradient (1 + 2 + 2 + 4 taps,
+    disjoint output pixels) as ONE grid must give, bit for bit, what the four separate nbdt_conv_igemm launches give --
+    plain and accumulating -- and touch nothing else (zero border intact).  Includes the engine's stage-change shapes
+    and a pixel count that is not a multiple of the 256-pixel tile."""
+    _, gp = _rand_act(B, H // 2, W // 2, cout, seed=61)
+    _, w_int = _rand_weight(cout, cin, 3, seed=62)
+    wd = torch.empty(cin, 9, cout, dtype=torch.bfloat16, device=DEV)
+    ops.weight_prep(w_int.to(DEV), cout, 9, cin, None, wd)
+    for accumulate in (False, True):
+        descs = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 2, accumulate=accumulate)
+        assert len(descs) == 4
+        base_f, base_p = _rand_act(B, H, W, cin, seed=63)
+        one, four = base_p.clone(), base_p.clone()
+        for d in descs:
+            ops.conv_igemm(d, gp, wd, four)
+        assert ops.last_igemm_kernel() == "conv_igemm_dma_kernel"
+        ops.conv_igemm_multi(descs, gp, wd, one)
+        assert ops.last_igemm_kernel() == "conv_igemm_dma_multi_kernel"
+        assert torch.equal(one, four), f"accumulate={accumulate}"
+        if not accumulate:
+            assert not torch.equal(ops.interior(one), ops.interior(base_p))
+        _check_border_zero(one)
+    with pytest.raises(_C.NBDTHipError, match="share channels"):
+        bad = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 2)
+        bad[1].accumulate = 1
+        ops.conv_igemm_multi(bad, gp, wd, one)

@@ -38,6 +38,10 @@ def _worker(rank, world, port, out_dir):
         comm.reduce_range(flat, lo, hi)
     comm.finish(flat)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), flat.numpy())
+    # a schedule decision must be rank 0's on every rank (engine.calibrate_cu_share under data parallelism):
+    # rank 0 measured "keep", rank 1 measured "discard" -> both keep; and the other way round -> both discard
+    assert comm.broadcast_flag(rank == 0, torch.device("cpu")) is True
+    assert comm.broadcast_flag(rank != 0, torch.device("cpu")) is False
     torch.distributed.destroy_process_group()
 
 

@@ -1325,7 +1325,9 @@ extern "C" int nbdt_head_soft_tree_loss(const nbdt_tree* t, const float* pooled,
 #define NBDT_HEAD(TPS_, SPB_)                                                                                      \
   if (rc == 1) rc = launch_head<TPS_, SPB_>(t, v, pooled, W, bias, K, B, y, w_xent, w_tree, scale, row_loss, z_out, \
                                             gpooled, gW, gb, st)
-  if (tps == 64) { NBDT_HEAD(64, 16); NBDT_HEAD(64, 8); NBDT_HEAD(64, 4); NBDT_HEAD(64, 1); }
+  // samples per block: 8 for one-wave groups (16 / 8 / 4 measure the same inside the training step, 8 is the fastest
+  // alone: profiles/r03_head.txt), fewer if the hierarchy's LDS rows do not fit
+  if (tps == 64) { NBDT_HEAD(64, 8); NBDT_HEAD(64, 4); NBDT_HEAD(64, 1); }
   else { NBDT_HEAD(256, 4); NBDT_HEAD(256, 2); NBDT_HEAD(256, 1); }
 #undef NBDT_HEAD
   NBDT_REQUIRE(rc != 1, "hierarchy + feature row too large for LDS");

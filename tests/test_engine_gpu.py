@@ -463,6 +463,39 @@ def test_hipgraph_captured_step_equals_eager_steps():
     assert losses[-1] < losses[0] and (graphed.store.flat - before).norm().item() > 0
 
 
+def test_hipgraph_captures_the_wrn_step_with_cu_sharing_and_lagged_events():
+    """The WideResNet step inside a hipGraph: the second stream is forked into the capture, the per-unit events that
+    order it against the main stream (one-unit lag) are captured as graph dependencies, the CU-sharing schedule is
+    forced (a calibration cannot run while capturing: GraphedStep's warm-up steps do it before).  lr = 0: every replay
+    must reproduce the eager loss of ITS batch (default mode: deterministic mode allocates its workspace per stream
+    with hipMalloc, which a capture does not allow -- include/nbdt_hip.h)."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(64, 3, 32, 32, generator=g).to(DEV) for _ in range(3)]
+    ys = [torch.randint(0, 10, (64,), generator=g).to(DEV) for _ in range(3)]
+    eager = E.WRNEngine(num_classes=10, blocks=16, width_factor=4, device=DEV, seed=2)
+    graphed = E.WRNEngine(num_classes=10, blocks=16, width_factor=4, device=DEV, seed=2)
+    for e in (eager, graphed):
+        e.set_cu_share(47.0, calibrate=False)
+    step = E.GraphedStep(graphed, crit, xs[0], ys[0], lr=0.0, momentum=0.0, weight_decay=0.0, warmup=1)
+    for x, y in zip(xs, ys):
+        le = E.train_step(eager, crit, x, y, 0.0, 0.0, 0.0).item()
+        lg = step(x, y).item()
+        assert abs(le - lg) < 2e-3 * abs(le), (le, lg)
+    with pytest.raises(RuntimeError, match="hipGraph"):
+        graphed.set_cu_share(47.0)          # an uncalibrated setting ...
+        graphed.forward(xs[0], training=True)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            cg = torch.cuda.CUDAGraph()
+            cg.capture_begin()
+            try:
+                graphed.calibrate_cu_share()     # ... refuses to calibrate inside a capture
+            finally:
+                cg.capture_end()
+
+
 @pytest.mark.parametrize("B", [1, 3, 5, 9])
 def test_ragged_batch_sizes_match_the_oracle(B, pkg_dir):
     """Pixel tiles that straddle the end of the batch (M not a multiple of 256 / 512 pixels, tiles covering more

@@ -1009,26 +1009,39 @@ class ResNetEngine(_Engine):
         check(lib().nbdt_pool_bn_bwd_apply(ptr(gpool), ptr(self._x_last), ptr(self._id_mean), ptr(self._id_rstd),
                                            ptr(self._id_gamma), ptr(self._id_beta), ptr(self._id_dsum), B, h, w,
                                            self.feat_c, ptr(g), ops.stream_ptr(self.device)))
-        toggle = 0
+        toggle, n_blk, side_mark = 0, 0, None
+        two_streams = self._side is not None and self._overlap
+        if two_streams:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
         for blk in reversed(self.blocks):
-            self.join_side_stream()      # shared gradient buffers: see WRNEngine.backward
+            # Shared gradient buffers vs weight gradients still running on the second stream: as in WRNEngine.backward,
+            # wait for what the side stream had been given one block ago, and alternate the buffers a weight gradient
+            # reads (gt2 / gt1 / gts) between consecutive blocks, so that the block in flight never overwrites them.
+            if two_streams:
+                main = torch.cuda.current_stream(self.device)
+                if side_mark is not None:
+                    main.wait_event(side_mark)
+                side_mark = torch.cuda.Event()
+                side_mark.record(self._side)
             k, s, cin, cout = blk["key"], blk["stride"], blk["cin"], blk["cout"]
             ho, wo = h, w
             hi, wi = ho * s, wo * s
             tag = ("@" + k) if self.debug_keep else ""
+            par = n_blk & 1
+            n_blk += 1
             t1 = self.buf(k + ".t1", B, ho, wo, cout)
             a1 = self.buf(k + ".a1", B, ho, wo, cout)
             t2 = self.buf(k + ".t2", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
-            gt2 = self.buf(f"gt2_{cout}{tag}", B, ho, wo, cout)
+            gt2 = self.buf(f"gt2_{cout}_{par}{tag}", B, ho, wo, cout)
             ga1 = self.buf(f"ga1_{cout}{tag}", B, ho, wo, cout)
-            gt1 = self.buf(f"gt1_{cout}{tag}", B, ho, wo, cout)
+            gt1 = self.buf(f"gt1_{cout}_{par}{tag}", B, ho, wo, cout)
             toggle ^= 1
             g_in = self.buf(f"g_in{cin}_{hi}_{toggle}{tag}", B, hi, wi, cin)
             x_in = blk["x_in"]
             if blk["sconv"] is not None:
                 gsc = self.buf(f"gsc_{cout}{tag}", B, ho, wo, cout)
-                gts = self.buf(f"gts_{cout}{tag}", B, ho, wo, cout)
+                gts = self.buf(f"gts_{cout}_{par}{tag}", B, ho, wo, cout)
                 blk["bn2"].backward(g, out, t2, gt2, relu=True, g_resid=gsc)
             else:
                 # identity shortcut: the masked gradient IS part of the block-input gradient

@@ -691,3 +691,24 @@ def test_sgd_kernel_zeroes_the_gradient_for_the_next_step(deterministic_mode):
     assert float(a.store.grad.abs().max()) > 0.0
     a.zero_grad()
     assert float(a.store.grad.abs().max()) == 0.0
+
+
+def test_resnet_two_stream_backward_equals_the_serial_one_bit_for_bit(deterministic_mode):
+    """ResNetEngine.backward with its weight gradients on the second stream, the one-block-lag event wait and shared
+    (alternating) gradient buffers against one stream with private buffers per block, in deterministic mode: the whole
+    flat gradient bit-identical, at 64x64 (config 4's image size) and 32x32."""
+    for size, classes, hierarchy, ds in ((64, 200, "induced-ResNet18", "TinyImagenet200"), (32, 10, "induced-ResNet18", "CIFAR10")):
+        crit = SoftTreeSupLoss(dataset=ds, criterion=nn.CrossEntropyLoss(), hierarchy=hierarchy)
+        g = torch.Generator().manual_seed(17)
+        x = torch.randn(48, 3, size, size, generator=g).to(DEV)
+        y = torch.randint(0, classes, (48,), generator=g).to(DEV)
+        two = E.ResNetEngine(num_classes=classes, device=DEV, seed=9)
+        one = E.ResNetEngine(num_classes=classes, device=DEV, seed=9)
+        one.debug_keep = True
+        one.set_overlap(False)
+        z2, l2, g2 = _one_backward(two, crit, x, y)
+        z2b, l2b, g2b = _one_backward(two, crit, x, y)
+        z1, l1, g1 = _one_backward(one, crit, x, y)
+        assert torch.equal(z1, z2) and l1 == l2 == l2b
+        assert torch.equal(g2, g2b), f"two runs differ, rel-L2 {_rel_l2(g2b, g2):.3e}"
+        assert torch.equal(g1, g2), f"two streams + shared buffers vs one stream + private buffers: rel-L2 {_rel_l2(g2, g1):.3e}"

@@ -61,8 +61,9 @@ int nbdt_version(void);
  * and a fold kernel sums the rows in index order: two runs of the same launches on the same inputs are then
  * bit-identical, whatever streams they were issued on.  Slower (an extra fold per reduction, 64+ MB of workspace per
  * (device, stream), allocated with hipMalloc on first use -- not capturable in a hipGraph); the arithmetic differs
- * from the default mode only in summation order.  Scope: the ResNet / WideResNet kernels and the rules layer (which
- * has no atomics); the EfficientNet-specific kernels (nbdt_dwconv_*, nbdt_se_*, nbdt_bn_act_*) keep their atomics. */
+ * from the default mode only in summation order.  Scope: every kernel of the three backbones -- the EfficientNet-
+ * specific reductions too (nbdt_dwconv_fwd's statistics, nbdt_dwconv_bwd_weight, nbdt_bn_act_pool, nbdt_bn_act_bwd,
+ * nbdt_se_gate_bwd's parameter gradients) -- and the rules layer, which has no atomics. */
 int nbdt_set_deterministic(int32_t on);
 int nbdt_get_deterministic(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(kThreads) void mb_pool_kernel(const bf16_t* __restr
                                                            const float* rstd, const float* gamma,
                                                            const float* beta, const bf16_t* __restrict__ gu,
                                                            MbGeom g, int ppt, float scale,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, long long row_stride) {
+  // row_stride: 0 = every pixel slice of an image adds into out[b]; deterministic mode: B*C, a zeroed copy of `out`
+  // per slice (one add per address; det_fold sums the copies in slice order)
   extern __shared__ float lds[];
   const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
   BnRegs bn;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void mb_pool_kernel(const bf16_t* __restr
       acc[0][i] += v;
     }
   }
-  float* dst = out + (size_t)b * g.C;
+  float* dst = out + (size_t)blockIdx.x * row_stride + (size_t)b * g.C;
   block_fold<1>(acc, cx, py, g.c8, g.PY, lds, [&](int, int c, float s) { atomicAdd(dst + c, s * scale); });
 }
 
@@ -179,7 +181,7 @@ template <int ACT, bool SE, bool POOL>
 __global__ __launch_bounds__(kThreads) void mb_bwd_reduce_kernel(
     const bf16_t* __restrict__ gu, const float* __restrict__ gate, const float* __restrict__ gpool,
     const bf16_t* __restrict__ x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-    MbGeom g, int ppt, float* __restrict__ scratch) {
+    MbGeom g, int ppt, float* __restrict__ scratch, unsigned slot_mask) {
   extern __shared__ float lds[];
   const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
   BnRegs bn;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void mb_bwd_reduce_kernel(
       acc[1][i] += gy * ((fx[i] - mu[i]) * rs[i]);
     }
   }
-  const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kSlots - 1);
+  const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & slot_mask;   // (deterministic mode: a row per block)
   block_fold<2>(acc, cx, py, g.c8, g.PY, lds, [&](int q, int c, float s) {
     atomicAdd(scratch + ((size_t)slot * 2 + q) * g.C + c, s);
   });
@@ -307,7 +309,7 @@ template <int K, int S, int TW, bool FLIP, bool STATS>
 __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restrict__ x,
                                                           const float* __restrict__ w, DwGeom d, int nseg,
                                                           int PY, bf16_t* __restrict__ y,
-                                                          float* __restrict__ stats) {
+                                                          float* __restrict__ stats, unsigned slot_mask) {
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
   constexpr int PAD = K / 2, SPAN = TW * S + K - S;
@@ -370,16 +372,37 @@ __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restri
       }
     }
   if (STATS) {
-    const int slot = (blockIdx.x + blockIdx.y * gridDim.x) & (kSlots - 1);
+    const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x) & slot_mask;   // (deterministic mode: a row per block)
     block_fold<2>(st, cx, py, g.c8, PY, lds, [&](int q, int c, float v) {
       atomicAdd(stats + ((size_t)slot * 2 + q) * g.C + c, v);
     });
   }
 }
 
+// Deterministic mode (nbdt_set_deterministic): where a reduction kernel of `blocks` blocks adds its per-block sums of n
+// floats -- the caller's 32-slot scratch, or a zeroed library-owned row per block that slot_finish() sums in block
+// order into slot 0 of the caller's scratch (same scheme as csrc/bn.hip).
+struct SlotTarget {
+  float* ptr;
+  unsigned mask;
+  bool det;
+};
+static int slot_target(hipStream_t st, float* scratch, int blocks, size_t n, SlotTarget* t) {
+  t->ptr = scratch; t->mask = kSlots - 1; t->det = false;
+  if (!deterministic()) return NBDT_OK;
+  float* rows = det_rows(st, (size_t)blocks * n);
+  if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+  NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)blocks * n * sizeof(float), st));
+  t->ptr = rows; t->mask = ~0u; t->det = true;
+  return NBDT_OK;
+}
+static int slot_finish(hipStream_t st, const SlotTarget& t, int blocks, size_t n, float* scratch) {
+  return t.det ? det_fold(st, t.ptr, blocks, n, scratch) : NBDT_OK;
+}
+
 template <int K, int S, bool FLIP>
-static void launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, void* y, float* stats,
-                          hipStream_t st) {
+static int launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, void* y, float* stats_out,
+                         hipStream_t st) {
   const int Wo = d.out.W, Ho = d.out.H;
   const int tw = (Wo % 7 == 0) ? 7 : (Wo >= 8 ? 8 : 4);
   const int nseg = (Wo + tw - 1) / tw;
@@ -387,14 +410,24 @@ static void launch_dw_row(const void* x, const float* w, const DwGeom& d, int B,
   if (PY < 1) PY = 1;
   if (PY > Ho * nseg) PY = Ho * nseg;
   const dim3 grid((Ho * nseg + PY - 1) / PY, B), blk(d.out.c8 * PY);
+  SlotTarget tgt{stats_out, kSlots - 1, false};
+  const int nblk = (int)(grid.x * grid.y);
+  if (stats_out) {
+    const int rc = slot_target(st, stats_out, nblk, 2 * (size_t)d.out.C, &tgt);
+    if (rc) return rc;
+  }
+  float* const stats = tgt.ptr;
+  const unsigned slot_mask = tgt.mask;
   const size_t shmem = stats ? (size_t)d.out.c8 * PY * 16 * sizeof(float) : 0;
 #define NBDT_GO(TW)                                                                                              \
   do {                                                                                                           \
-    if (stats) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, true>), grid, blk, shmem, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats); \
-    else hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, false>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats); \
+    if (stats) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, true>), grid, blk, shmem, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask); \
+    else hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, false>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask); \
   } while (0)
   if (tw == 7) NBDT_GO(7); else if (tw == 8) NBDT_GO(8); else NBDT_GO(4);
 #undef NBDT_GO
+  NBDT_LAUNCH_CHECK();
+  return stats_out ? slot_finish(st, tgt, nblk, 2 * (size_t)d.out.C, stats_out) : NBDT_OK;
 }
 
 // gx[hi][wi] = sum_{r,s : (hi+pad-r) % stride == 0, ...} gy[(hi+pad-r)/stride][(wi+pad-s)/stride] * w[r][s]
@@ -443,7 +476,8 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __r
 template <int K, int S>
 __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* __restrict__ x,
                                                                  const bf16_t* __restrict__ gy, DwGeom d, int PY,
-                                                                 int bchunk, float* __restrict__ dw) {
+                                                                 int bchunk, float* __restrict__ dw,
+                                                                 long long row_stride) {
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
   const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, r = blockIdx.z;
@@ -490,7 +524,8 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* _
       }
     }
   }
-  float* dst = dw + (size_t)r * K * g.C;
+  // row_stride: 0, or (deterministic mode) K*K*C: a zeroed copy of dw per (row block, batch chunk), folded in order
+  float* dst = dw + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * row_stride + (size_t)r * K * g.C;
   block_fold<K>(acc, cx, py, g.c8, PY, lds, [&](int s, int c, float v) { atomicAdd(dst + (size_t)s * g.C + c, v); });
 }
 
@@ -645,6 +680,7 @@ constexpr int kPpt = 8;
     else { MACRO(NBDT_ACT_NONE); }                                    \
   } while (0)
 
+
 extern "C" int nbdt_bn_act_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
                                  const float* beta, int32_t act, const float* gate, const void* residual, int32_t B,
                                  int32_t H, int32_t W, int32_t C, void* y, void* stream) {
@@ -680,14 +716,24 @@ extern "C" int nbdt_bn_act_pool(const void* x, const float* save_mean, const flo
   const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
   const dim3 grid(g.slices, B), blk(g.threads);
   const size_t shmem = (size_t)g.threads * 8 * sizeof(float);
+  float* target = out;           // deterministic mode: a zeroed copy of `out` per pixel slice, folded in slice order
+  long long row_stride = 0;
+  const size_t n_out = (size_t)B * C;
+  if (deterministic() && g.slices > 1) {
+    target = det_rows(st, (size_t)g.slices * n_out);
+    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-slice rows");
+    NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)g.slices * n_out * sizeof(float), st));
+    row_stride = (long long)n_out;
+  }
 #define NBDT_GO(A)                                                                                              \
   do {                                                                                                          \
-    if (mul) hipLaunchKernelGGL((mb_pool_kernel<A, true>), grid, blk, shmem, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, (const bf16_t*)mul, g, 2 * kPpt, scale, out); \
-    else hipLaunchKernelGGL((mb_pool_kernel<A, false>), grid, blk, shmem, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, (const bf16_t*)mul, g, 2 * kPpt, scale, out); \
+    if (mul) hipLaunchKernelGGL((mb_pool_kernel<A, true>), grid, blk, shmem, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, (const bf16_t*)mul, g, 2 * kPpt, scale, target, row_stride); \
+    else hipLaunchKernelGGL((mb_pool_kernel<A, false>), grid, blk, shmem, st, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, (const bf16_t*)mul, g, 2 * kPpt, scale, target, row_stride); \
   } while (0)
   NBDT_ACT_SWITCH(act, NBDT_GO);
 #undef NBDT_GO
   NBDT_LAUNCH_CHECK();
+  if (target != out) return det_fold(st, target, g.slices, n_out, out);
   return NBDT_OK;
 }
 
@@ -708,15 +754,21 @@ extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* g
     const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
     const dim3 grid(g.slices, B), blk(g.threads);
     const size_t shmem = (size_t)g.threads * 16 * sizeof(float);
+    SlotTarget tgt;
+    const int nblk = g.slices * B;
+    rc = slot_target(st, scratch, nblk, 2 * (size_t)C, &tgt);
+    if (rc) return rc;
 #define NBDT_GO(A)                                                                                              \
   do {                                                                                                          \
-    if (se) hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, true, false>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, scratch); \
-    else if (pool) hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, false, true>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, scratch); \
-    else hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, false, false>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, scratch); \
+    if (se) hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, true, false>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, tgt.ptr, tgt.mask); \
+    else if (pool) hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, false, true>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, tgt.ptr, tgt.mask); \
+    else hipLaunchKernelGGL((mb_bwd_reduce_kernel<A, false, false>), grid, blk, shmem, st, (const bf16_t*)gu, gate, gpool, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, tgt.ptr, tgt.mask); \
   } while (0)
     NBDT_ACT_SWITCH(act, NBDT_GO);
 #undef NBDT_GO
     NBDT_LAUNCH_CHECK();
+    rc = slot_finish(st, tgt, nblk, 2 * (size_t)C, scratch);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(mb_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
@@ -764,10 +816,10 @@ extern "C" int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t
   if (rc) return rc;
   const DwGeom d = dw_geom(B, H, W, C, k, stride, 4);
   hipStream_t st = (hipStream_t)stream;
-  if (k == 3) { if (stride == 1) launch_dw_row<3, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<3, 2, false>(x, w, d, B, y, bn_scratch, st); }
-  else { if (stride == 1) launch_dw_row<5, 1, false>(x, w, d, B, y, bn_scratch, st); else launch_dw_row<5, 2, false>(x, w, d, B, y, bn_scratch, st); }
-  NBDT_LAUNCH_CHECK();
-  return NBDT_OK;
+  if (k == 3) return stride == 1 ? launch_dw_row<3, 1, false>(x, w, d, B, y, bn_scratch, st)
+                                 : launch_dw_row<3, 2, false>(x, w, d, B, y, bn_scratch, st);
+  return stride == 1 ? launch_dw_row<5, 1, false>(x, w, d, B, y, bn_scratch, st)
+                     : launch_dw_row<5, 2, false>(x, w, d, B, y, bn_scratch, st);
 }
 
 extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
@@ -779,7 +831,8 @@ extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, i
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {   // same correlation with the kernel rotated by 180 degrees
     const DwGeom d = dw_geom(B, H, W, C, k, 1, 4);
-    if (k == 3) launch_dw_row<3, 1, true>(gy, w, d, B, gx, nullptr, st); else launch_dw_row<5, 1, true>(gy, w, d, B, gx, nullptr, st);
+    return k == 3 ? launch_dw_row<3, 1, true>(gy, w, d, B, gx, nullptr, st)
+                  : launch_dw_row<5, 1, true>(gy, w, d, B, gx, nullptr, st);
   } else {
     hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(in.slices, B), dim3(in.threads), 0, st, (const bf16_t*)gy, w, in,
                        H / stride, W / stride, k, stride, k / 2, 4, (bf16_t*)gx);
@@ -806,11 +859,22 @@ extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, 
   const dim3 grid((Ho + PY - 1) / PY, (B + bchunk - 1) / bchunk, k), blk(threads);
   const size_t shmem = (size_t)threads * k * 8 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define NBDT_GO(K, S) hipLaunchKernelGGL((dw_bwd_weight_kernel<K, S>), grid, blk, shmem, st, (const bf16_t*)x, (const bf16_t*)gy, d, PY, bchunk, dw)
+  float* target = dw;
+  long long row_stride = 0;
+  const size_t n_dw = (size_t)k * k * C;
+  const int nrows = (int)(grid.x * grid.y);
+  if (deterministic() && nrows > 1) {
+    target = det_rows(st, (size_t)nrows * n_dw);
+    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+    NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)nrows * n_dw * sizeof(float), st));
+    row_stride = (long long)n_dw;
+  }
+#define NBDT_GO(K, S) hipLaunchKernelGGL((dw_bwd_weight_kernel<K, S>), grid, blk, shmem, st, (const bf16_t*)x, (const bf16_t*)gy, d, PY, bchunk, target, row_stride)
   if (k == 3) { if (stride == 1) NBDT_GO(3, 1); else NBDT_GO(3, 2); }
   else { if (stride == 1) NBDT_GO(5, 1); else NBDT_GO(5, 2); }
 #undef NBDT_GO
   NBDT_LAUNCH_CHECK();
+  if (target != dw) return det_fold(st, target, nrows, n_dw, dw);
   return NBDT_OK;
 }
 
@@ -839,7 +903,7 @@ extern "C" int nbdt_se_gate_bwd(const float* dgate, const float* gate, const flo
                      gpool);
   NBDT_LAUNCH_CHECK();
   const int n = C_real * S;
-  const int bchunk = 16;
+  const int bchunk = deterministic() ? B : 16;     // (one chunk: one add per address)
   hipLaunchKernelGGL(se_param_grad_kernel, dim3((n + 255) / 256, (B + bchunk - 1) / bchunk), dim3(256), 0, st, dpre2,
                      dpre1, pre1, pooled, B, C, C_real, S, bchunk, dw1, db1, dw2, db2);
   NBDT_LAUNCH_CHECK();

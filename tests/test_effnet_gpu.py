@@ -353,3 +353,40 @@ def test_facade_module_is_a_drop_in_backbone_for_nbdt():
         Hh = hard(x)
     assert P.shape == (4, 1000) and abs(P.sum(1) - 1).max().item() < 1e-4
     assert torch.equal(Hh.sum(1), torch.ones(4, device=DEV))
+
+
+def test_deterministic_mode_covers_the_mbconv_kernels():
+    """nbdt_set_deterministic: two engines with one seed, three full training steps each (224x224 would only be
+    slower: 64x64 images run every kernel) -- parameters, momentum and running statistics bit-identical, and so are
+    two backward passes of one engine.  Without the mode they differ from the first step on (pooled sums, depthwise
+    statistics and weight gradients, squeeze-excite parameter gradients all go through fp32 atomics)."""
+    from nbdt import ops
+    crit = SoftTreeSupLoss(dataset="Imagenet1000", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-efficientnet_b7b")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(24, 3, 64, 64, generator=g).to(DEV)
+    y = torch.randint(0, 1000, (24,), generator=g).to(DEV)
+    ops.set_deterministic(True)
+    try:
+        runs = []
+        for _ in range(2):
+            eng = EfficientNetEngine(num_classes=1000, dropout_rate=0.2, device=DEV, seed=4)
+            losses = [train_step(eng, crit, x, y, lr=0.05).item() for _ in range(3)]
+            torch.cuda.synchronize()
+            runs.append((losses, eng.store.flat.clone(), eng.store.mom.clone(),
+                         torch.cat([b.running_var for b in eng.bns]).clone()))
+        assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+        for a, b in zip(runs[0][1:], runs[1][1:]):
+            assert torch.equal(a, b)
+        grads = []
+        for _ in range(2):
+            eng.zero_grad()
+            z = eng.forward(x, training=True)
+            eng._step -= 1                      # the same dropout mask for both passes
+            _, gz = crit.loss_and_grad(z, y)
+            eng.backward(gz)
+            torch.cuda.synchronize()
+            grads.append(eng.store.grad.clone())
+        assert torch.equal(grads[0], grads[1])
+    finally:
+        ops.set_deterministic(False)

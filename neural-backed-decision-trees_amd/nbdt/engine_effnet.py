@@ -283,8 +283,24 @@ class EfficientNetEngine(_Engine):
         self.final_conv.backward_weight(self._x_last, gf)
         g = self.buf(f"g_{self._x_last.shape[3]}_{h}", B, h, w, self._x_last.shape[3])
         self.final_conv.backward_data(gf, g)
+        two_streams = self._side is not None and self._overlap
+        n_unit, side_mark = 0, None
+        if two_streams:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
         for u in reversed(self.units):
-            self.join_side_stream()      # gradient buffers are shared between units: see WRNEngine.backward
+            # Gradient buffers are shared between units and the weight gradients run on the second stream: as in
+            # WRNEngine.backward the main stream waits for what the side stream had been given ONE UNIT AGO, and the
+            # three buffers a weight gradient reads (gp, gd, ge) alternate between consecutive units, so that a unit
+            # never overwrites what the previous unit's weight gradients may still be reading (checked bit for bit
+            # against one stream with private buffers: tests/test_effnet_gpu.py).
+            if two_streams:
+                main = torch.cuda.current_stream(self.device)
+                if side_mark is not None:
+                    main.wait_event(side_mark)
+                side_mark = torch.cuda.Event()
+                side_mark.record(self._side)
+            par = n_unit & 1
+            n_unit += 1
             k, s = u["key"], u["stride"]
             cin, mid, cout = _pad32(u["cin"]), _pad32(u["mid"]), _pad32(u["cout"])
             ho, wo = h, w
@@ -293,8 +309,8 @@ class EfficientNetEngine(_Engine):
             p_raw = self.buf(k + ".p_raw", B, ho, wo, cout)
             d_raw = self.buf(k + ".d_raw", B, ho, wo, mid)
             d_se = self.buf(k + ".d_se", B, ho, wo, mid)
-            gp = self.buf(f"gp_{cout}_{ho}{tag}", B, ho, wo, cout)
-            gd = self.buf(f"gd_{mid}_{ho}{tag}", B, ho, wo, mid)
+            gp = self.buf(f"gp_{cout}_{ho}_{par}{tag}", B, ho, wo, cout)
+            gd = self.buf(f"gd_{mid}_{ho}_{par}{tag}", B, ho, wo, mid)
             bn = u["bn3"]
             ops.bn_act_bwd(g, p_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
                            st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gp, act=ops.ACT_NONE)
@@ -314,7 +330,7 @@ class EfficientNetEngine(_Engine):
             if u["conv1"] is not None:
                 e_raw = self.buf(k + ".e_raw", B, hi, wi, mid)
                 e_act = self.buf(k + ".e_act", B, hi, wi, mid)
-                ge = self.buf(f"ge_{mid}_{hi}{tag}", B, hi, wi, mid)
+                ge = self.buf(f"ge_{mid}_{hi}_{par}{tag}", B, hi, wi, mid)
                 u["dw"].backward_weight(e_act, gd)
                 u["dw"].backward_data(gd, ge)
                 bn = u["bn1"]

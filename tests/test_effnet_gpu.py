@@ -390,3 +390,36 @@ def test_deterministic_mode_covers_the_mbconv_kernels():
         assert torch.equal(grads[0], grads[1])
     finally:
         ops.set_deterministic(False)
+
+
+def test_two_stream_backward_equals_the_serial_one_bit_for_bit():
+    """EfficientNetEngine.backward with the weight gradients on the second stream, the one-unit-lag event wait and
+    shared (alternating) gradient buffers, against one stream with private buffers per unit -- deterministic mode, the
+    whole flat gradient bit-identical (no launch reads a buffer before its producer finished or after a later unit
+    overwrote it)."""
+    from nbdt import ops
+    crit = SoftTreeSupLoss(dataset="Imagenet1000", criterion=nn.CrossEntropyLoss(),
+                           hierarchy="induced-efficientnet_b7b")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 3, 96, 96, generator=g).to(DEV)
+    y = torch.randint(0, 1000, (16,), generator=g).to(DEV)
+    ops.set_deterministic(True)
+    try:
+        out = []
+        for serial in (False, True, False):
+            eng = EfficientNetEngine(num_classes=1000, dropout_rate=0.0, device=DEV, seed=6)
+            if serial:
+                eng.debug_keep = True
+                eng.set_overlap(False)
+            eng.zero_grad()
+            z = eng.forward(x, training=True)
+            loss, gz = crit.loss_and_grad(z, y)
+            eng.backward(gz)
+            torch.cuda.synchronize()
+            out.append((loss.item(), eng.store.grad.clone()))
+        assert out[0][0] == out[1][0] == out[2][0]
+        assert torch.equal(out[0][1], out[2][1]), "two runs of the two-stream schedule differ"
+        rel = ((out[0][1] - out[1][1]).norm() / out[1][1].norm()).item()
+        assert torch.equal(out[0][1], out[1][1]), f"two streams + shared buffers vs one stream + private buffers: {rel:.3e}"
+    finally:
+        ops.set_deterministic(False)

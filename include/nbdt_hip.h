@@ -347,6 +347,18 @@ int nbdt_dwconv_fwd(const void* x, const float* w, int32_t B, int32_t H, int32_t
                     into the NBDT_BN_SLOTS scratch for nbdt_bn_stats(x = NULL, ...) */, void* stream);
 int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
                          int32_t k, int32_t stride, void* gx, void* stream);
+/* Stride-1 depthwise data gradient whose epilogue also produces the backward sums of the BatchNorm + swish that fed the
+ * depthwise conv (MBConv: dwconv(swish(bn1(e))) -- pytorchcv dwconv block after the expand conv): gx = dL/d(swish(bn(bn_x))),
+ * and sum(g'), sum(g' * xhat) with g' = gx * swish'(bn(bn_x)) go to the 32-slot `scratch` -- follow with
+ * nbdt_bn_act_bwd_apply (fold + elementwise pass), which replaces nbdt_bn_act_bwd's reduction pass over gx and bn_x. */
+int nbdt_dwconv_bwd_data_bn(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                            void* gx, const void* bn_x, const float* save_mean, const float* save_rstd,
+                            const float* gamma, const float* beta, float* scratch, void* stream);
+/* nbdt_bn_act_bwd without its reduction pass: the sums are already in `scratch` (plain form only: no gate, no pool). */
+int nbdt_bn_act_bwd_apply(const void* gu, const void* x, const float* save_mean, const float* save_rstd,
+                          const float* gamma, const float* beta, int32_t act, const void* gx_add, int32_t B, int32_t H,
+                          int32_t W, int32_t C, float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx,
+                          void* stream);
 int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, int32_t H, int32_t W, int32_t C,
                            int32_t k, int32_t stride, float* dw, void* stream);
 /* SEBlock gate: gate[b][c] = sigmoid(W2 swish(W1 pooled[b] + b1) + b2) for c < C_real, 0 above.

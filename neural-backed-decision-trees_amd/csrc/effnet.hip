@@ -305,11 +305,19 @@ struct DwGeom {
 // a thread owns 8 channels x TW consecutive outputs of one row; per kernel row it loads the
 // TW*S + K - S input pixels under them ONCE and feeds each to every output it overlaps
 // (K=5: 7.5 loads per output instead of 25), K x 8 weights of the row in registers.
-template <int K, int S, int TW, bool FLIP, bool STATS>
+// STATS: 0 none; 1 = sum / sum of squares of the (rounded) outputs, the batch statistics of the NEXT BatchNorm;
+// 2 (data gradient only) = the backward sums of the BatchNorm + swish that PRODUCED this conv's input: the output is
+// dL/d(swish(bn(bx))), so with g' = out * swish'(bn(bx)) the kernel accumulates sum(g'), sum(g' * xhat) while it still
+// holds the tile -- the separate reduction pass (a re-read of this output and of bx) disappears, bx is read once here.
+struct DwBn {
+  const bf16_t* x;     // the BatchNorm's input (same geometry as this launch's output)
+  const float *mean, *rstd, *gamma, *beta;
+};
+template <int K, int S, int TW, bool FLIP, int STATS>
 __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restrict__ x,
                                                           const float* __restrict__ w, DwGeom d, int nseg,
                                                           int PY, bf16_t* __restrict__ y,
-                                                          float* __restrict__ stats, unsigned slot_mask) {
+                                                          float* __restrict__ stats, unsigned slot_mask, DwBn bnb) {
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
   constexpr int PAD = K / 2, SPAN = TW * S + K - S;
@@ -355,20 +363,43 @@ __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restri
       }
     }
   }
-  bf16_t* yrow = y + (size_t)b * g.img + (ho + 1) * g.row + g.C + cx * 8;
+  const size_t row_off = (size_t)b * g.img + (ho + 1) * g.row + g.C + cx * 8;
+  bf16_t* yrow = y + row_off;
   float st[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) st[0][i] = st[1][i] = 0.f;
+  float bsc[8], bsh[8], bmu[8], brs[8];
+  if (STATS == 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cx * 8 + i;
+      bmu[i] = bnb.mean[c];
+      brs[i] = bnb.rstd[c];
+      bsc[i] = bnb.gamma[c] * brs[i];
+      bsh[i] = bnb.beta[c] - bmu[i] * bsc[i];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < TW; ++t)
     if (live && wo0 + t < g.W) {
       const u32x4_t v = pack8(acc[t]);
       *(u32x4_t*)(yrow + (wo0 + t) * g.C) = v;
-      if (STATS) {      // batch statistics of the NEXT BatchNorm, from the rounded values it will read
+      if (STATS == 1) {      // batch statistics of the NEXT BatchNorm, from the rounded values it will read
         float f[8];
         unpack8(v, f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { st[0][i] += f[i]; st[1][i] += f[i] * f[i]; }
+      }
+      if (STATS == 2) {      // backward sums of the producing BatchNorm + swish, from the rounded gradient
+        float f[8], fx[8];
+        unpack8(v, f);
+        unpack8(*(const u32x4_t*)(bnb.x + row_off + (wo0 + t) * g.C), fx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float gy = f[i] * act_bwd<NBDT_ACT_SWISH>(fx[i] * bsc[i] + bsh[i]);
+          st[0][i] += gy;
+          st[1][i] += gy * ((fx[i] - bmu[i]) * brs[i]);
+        }
       }
     }
   if (STATS) {
@@ -402,7 +433,7 @@ static int slot_finish(hipStream_t st, const SlotTarget& t, int blocks, size_t n
 
 template <int K, int S, bool FLIP>
 static int launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, void* y, float* stats_out,
-                         hipStream_t st) {
+                         hipStream_t st, const DwBn* bn = nullptr) {
   const int Wo = d.out.W, Ho = d.out.H;
   const int tw = (Wo % 7 == 0) ? 7 : (Wo >= 8 ? 8 : 4);
   const int nseg = (Wo + tw - 1) / tw;
@@ -421,8 +452,9 @@ static int launch_dw_row(const void* x, const float* w, const DwGeom& d, int B, 
   const size_t shmem = stats ? (size_t)d.out.c8 * PY * 16 * sizeof(float) : 0;
 #define NBDT_GO(TW)                                                                                              \
   do {                                                                                                           \
-    if (stats) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, true>), grid, blk, shmem, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask); \
-    else hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, false>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask); \
+    if (stats && bn) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, 2>), grid, blk, shmem, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask, *bn); \
+    else if (stats) hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, 1>), grid, blk, shmem, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask, DwBn{}); \
+    else hipLaunchKernelGGL((dw_row_kernel<K, S, TW, FLIP, 0>), grid, blk, 0, st, (const bf16_t*)x, w, d, nseg, PY, (bf16_t*)y, stats, slot_mask, DwBn{}); \
   } while (0)
   if (tw == 7) NBDT_GO(7); else if (tw == 8) NBDT_GO(8); else NBDT_GO(4);
 #undef NBDT_GO
@@ -737,10 +769,11 @@ extern "C" int nbdt_bn_act_pool(const void* x, const float* save_mean, const flo
   return NBDT_OK;
 }
 
-extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* gpool, const void* x,
-                               const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
-                               int32_t act, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
-                               float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx, void* stream) {
+static int bn_act_bwd_impl(const void* gu, const float* gate, const float* gpool, const void* x,
+                           const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                           int32_t act, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
+                           float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx, void* stream,
+                           bool sums_ready) {
   NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && scratch && dsum && gx, "null argument");
   NBDT_REQUIRE(gu || (gpool && !gate), "need an upstream gradient tensor or a pooled gradient");
   NBDT_REQUIRE(!gate || (gu && gpool), "the SE form needs gu, gate and gpool");
@@ -750,7 +783,7 @@ extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* g
   hipStream_t st = (hipStream_t)stream;
   const bool se = gate != nullptr, pool = gu == nullptr;
   NBDT_REQUIRE(!(pool && gx_add), "pooled form has no gx_add");
-  {
+  if (!sums_ready) {      // (sums_ready: the producing kernel -- nbdt_dwconv_bwd_data_bn -- already filled the slots)
     const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
     const dim3 grid(g.slices, B), blk(g.threads);
     const size_t shmem = (size_t)g.threads * 16 * sizeof(float);
@@ -788,6 +821,23 @@ extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* g
     NBDT_LAUNCH_CHECK();
   }
   return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_act_bwd(const void* gu, const float* gate, const float* gpool, const void* x,
+                               const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                               int32_t act, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
+                               float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx, void* stream) {
+  return bn_act_bwd_impl(gu, gate, gpool, x, save_mean, save_rstd, gamma, beta, act, gx_add, B, H, W, C, scratch, dsum,
+                         dgamma, dbeta, gx, stream, false);
+}
+
+extern "C" int nbdt_bn_act_bwd_apply(const void* gu, const void* x, const float* save_mean, const float* save_rstd,
+                                     const float* gamma, const float* beta, int32_t act, const void* gx_add,
+                                     int32_t B, int32_t H, int32_t W, int32_t C, float* scratch, float* dsum,
+                                     float* dgamma, float* dbeta, void* gx, void* stream) {
+  NBDT_REQUIRE(gu != nullptr, "null upstream gradient");
+  return bn_act_bwd_impl(gu, nullptr, nullptr, x, save_mean, save_rstd, gamma, beta, act, gx_add, B, H, W, C, scratch,
+                         dsum, dgamma, dbeta, gx, stream, true);
 }
 
 static int check_dw(int B, int H, int W, int C, int k, int stride) {
@@ -839,6 +889,20 @@ extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, i
   }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
+}
+
+extern "C" int nbdt_dwconv_bwd_data_bn(const void* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
+                                      int32_t k, void* gx, const void* bn_x, const float* save_mean,
+                                      const float* save_rstd, const float* gamma, const float* beta, float* scratch,
+                                      void* stream) {
+  NBDT_REQUIRE(gy && w && gx && bn_x && save_mean && save_rstd && gamma && beta && scratch, "null argument");
+  int rc = check_dw(B, H, W, C, k, 1);
+  if (rc) return rc;
+  const DwGeom d = dw_geom(B, H, W, C, k, 1, 4);
+  const DwBn bn{(const bf16_t*)bn_x, save_mean, save_rstd, gamma, beta};
+  hipStream_t st = (hipStream_t)stream;
+  return k == 3 ? launch_dw_row<3, 1, true>(gy, w, d, B, gx, scratch, st, &bn)
+                : launch_dw_row<5, 1, true>(gy, w, d, B, gx, scratch, st, &bn);
 }
 
 extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -112,6 +112,9 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, _P]),
     "nbdt_dwconv_fwd": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_dwconv_bwd_data": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_dwconv_bwd_data_bn": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nbdt_bn_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32,
+                                      _P, _P, _P, _P, _P, _P]),
     "nbdt_dwconv_bwd_weight": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_se_gate_fwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_se_gate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P,

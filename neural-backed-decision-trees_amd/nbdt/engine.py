@@ -262,6 +262,7 @@ class _Engine:
         self.debug_join_each_unit = False # A/B: join the side stream at the top of every unit (the schedule before round 3)
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
+        self.fuse_dw_bn_bwd = True  # MBConv: BatchNorm-backward sums in the depthwise data gradient's epilogue (A/B)
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
         self._cu_share = None     # set_cu_share(): BatchNorm-backward passes beside weight gradients on disjoint CUs
         self._share_join = False

@@ -332,10 +332,18 @@ class EfficientNetEngine(_Engine):
                 e_act = self.buf(k + ".e_act", B, hi, wi, mid)
                 ge = self.buf(f"ge_{mid}_{hi}_{par}{tag}", B, hi, wi, mid)
                 u["dw"].backward_weight(e_act, gd)
-                u["dw"].backward_data(gd, ge)
                 bn = u["bn1"]
-                ops.bn_act_bwd(ge, e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
-                               st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), ge, act=ACT)
+                if u["dw"].stride == 1 and self.fuse_dw_bn_bwd:
+                    # the depthwise data gradient's epilogue leaves bn1's backward sums in the slots: no reduction
+                    # pass over ge and e_raw (5.5 % of a step), e_raw is read once there
+                    ops.dwconv_bwd_data_bn(gd, st.p(u["dw"].name), ge, u["dw"].k, e_raw, bn.mean, bn.rstd, bn.gamma,
+                                           bn.beta, self.scratch(bn.C))
+                    ops.bn_act_bwd_apply(ge, e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                                         st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), ge, act=ACT)
+                else:
+                    u["dw"].backward_data(gd, ge)
+                    ops.bn_act_bwd(ge, e_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                                   st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), ge, act=ACT)
                 u["conv1"].backward_weight(x_in, ge)
                 if u["residual"]:
                     # out = bn3(...) + x_in: the unit-output gradient g is also the skip gradient ->

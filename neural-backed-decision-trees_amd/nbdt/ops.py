@@ -489,6 +489,22 @@ def dwconv_bwd_data(gy, w, gx, k, stride):
     check(lib().nbdt_dwconv_bwd_data(ptr(gy), ptr(w), B, H, W, C, k, stride, ptr(gx), stream_ptr(gx.device)))
 
 
+def dwconv_bwd_data_bn(gy, w, gx, k, bn_x, mean, rstd, gamma, beta, scratch):
+    """Stride-1 depthwise data gradient + the backward sums of the BatchNorm + swish that produced its input (into the
+    32-slot scratch); follow with bn_act_bwd_apply."""
+    B, H, W, C = _dims(gx)
+    check(lib().nbdt_dwconv_bwd_data_bn(ptr(gy), ptr(w), B, H, W, C, k, ptr(gx), ptr(bn_x), ptr(mean), ptr(rstd),
+                                        ptr(gamma), ptr(beta), ptr(scratch), stream_ptr(gx.device)))
+
+
+def bn_act_bwd_apply(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx, act=ACT_SWISH, gx_add=None):
+    """bn_act_bwd without its reduction pass (the producing kernel filled the slots)."""
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_act_bwd_apply(ptr(gu), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(gx_add),
+                                      B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx),
+                                      stream_ptr(x.device)))
+
+
 def dwconv_bwd_weight(x, gy, dw, k, stride):
     B, H, W, C = _dims(x)
     check(lib().nbdt_dwconv_bwd_weight(ptr(x), ptr(gy), B, H, W, C, k, stride, ptr(dw), stream_ptr(x.device)))

@@ -423,3 +423,41 @@ def test_two_stream_backward_equals_the_serial_one_bit_for_bit():
         assert torch.equal(out[0][1], out[1][1]), f"two streams + shared buffers vs one stream + private buffers: {rel:.3e}"
     finally:
         ops.set_deterministic(False)
+
+
+@pytest.mark.parametrize("B,H,W,C,k", [(3, 16, 16, 96, 3), (2, 28, 28, 240, 5), (5, 7, 7, 672, 5), (4, 14, 14, 32, 3)])
+def test_depthwise_data_gradient_with_fused_batchnorm_backward_sums(B, H, W, C, k):
+    """nbdt_dwconv_bwd_data_bn + nbdt_bn_act_bwd_apply against nbdt_dwconv_bwd_data + nbdt_bn_act_bwd: the same
+    data gradient bit for bit, the same BatchNorm backward (sums to fp32 summation order, gx within bf16 rounding of
+    them, dgamma / dbeta to 1e-5), in the default and in the deterministic mode."""
+    g = torch.Generator().manual_seed(B * 100 + C)
+    def act(scale=1.0):
+        t = ops.padded(B, H, W, C, DEV)
+        ops.interior(t).copy_((torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16).to(DEV))
+        return t
+    gy, e_raw = act(0.5), act(1.0)
+    w = (torch.randn(k * k, C, generator=g) * 0.2).to(DEV)
+    mean, rstd = (torch.randn(C, generator=g) * 0.1).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            scratch = torch.zeros(ops.BN_SLOTS * 2 * 2048, device=DEV)
+            ge_ref = ops.padded(B, H, W, C, DEV)
+            ops.dwconv_bwd_data(gy, w, ge_ref, k, 1)
+            dsum_ref, dg_ref, db_ref = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            gx_ref = ops.padded(B, H, W, C, DEV)
+            ops.bn_act_bwd(ge_ref, e_raw, mean, rstd, gamma, beta, scratch, dsum_ref, dg_ref, db_ref, gx_ref)
+            ge = ops.padded(B, H, W, C, DEV)
+            ops.dwconv_bwd_data_bn(gy, w, ge, k, e_raw, mean, rstd, gamma, beta, scratch)
+            dsum, dg, db = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            gx = ops.padded(B, H, W, C, DEV)
+            ops.bn_act_bwd_apply(ge, e_raw, mean, rstd, gamma, beta, scratch, dsum, dg, db, gx)
+            assert torch.equal(ge, ge_ref)
+            tol = 2e-5 * dsum_ref.abs().max().item() + 1e-6
+            assert (dsum - dsum_ref).abs().max().item() < tol
+            assert (dg - dg_ref).abs().max().item() < tol and (db - db_ref).abs().max().item() < tol
+            assert (gx.float() - gx_ref.float()).abs().max().item() <= 2 ** -7 * gx_ref.float().abs().max().item()
+            assert float(scratch.abs().max()) == 0.0          # slots left zeroed for the next user
+        finally:
+            ops.set_deterministic(False)

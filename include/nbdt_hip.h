@@ -300,6 +300,18 @@ int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float* save_mean,
 int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
                            const float* gamma, const float* beta, int32_t B, int32_t H, int32_t W, int32_t C,
                            float* scratch, float* dsum, float* dgamma, float* dbeta, int32_t cus, void* stream);
+/* nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus as TWO launches instead of three: the fold of the 32 slots
+ * (bn_bwd_finalize, 7 us on the backward critical path of every conv) happens in the prologue of the elementwise pass --
+ * every block folds the slots for itself, block 0 writes dsum / accumulates dgamma, dbeta.  The slots being read cannot
+ * be re-zeroed inside that launch, so the caller passes a PAIR of 32-slot buffers and alternates them from call to
+ * call: `slots` (zero on entry, dirty on return) receives this call's sums, `slots_other` (not touched by anyone
+ * while this call runs) is left zeroed for the next call.  Same arithmetic and summation order as the three-launch
+ * form: bit-identical gx / dsum in deterministic mode.  Replaces the autograd of F.relu(bn(x)) (pytorchcv
+ * PreResActivation behind nbdt/models/wideresnet.py:1-5). */
+int nbdt_bn_bwd_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                    const float* beta, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C, float* slots,
+                    float* slots_other, float* dsum, float* dgamma, float* dbeta, void* gx, int32_t cus,
+                    void* stream);
 /* head: pooled[b][c] = mean over (h,w) of relu(bn(x))  (post_activ + final_pool / avg_pool2d,
  * nbdt/models/resnet.py:142) and its backward given gpooled[B][C] (same two passes) */
 int nbdt_bn_relu_pool(const void* x, const float* save_mean, const float* save_rstd,

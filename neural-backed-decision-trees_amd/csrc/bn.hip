@@ -284,12 +284,38 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
 // A block of the ordinary launch above is 4 waves and the dispatcher spreads 2048 of them over every CU, where
 // they keep an 8-wave weight-gradient block (a CU's whole register file) from starting at all.
 // Fused-ReLU form only (mask recomputed from x; what the engines' fused backward uses).
-template <bool HAS_ADD>
+// FOLD (nbdt_bn_bwd_cus): the kernel also does what bn_bwd_finalize_kernel did in a launch of its own between the
+// sums and this pass (7 us + a kernel boundary on the backward critical path, 21 times per WRN-28-10 step): every
+// block folds the 32 slots of `slots` (ascending slot order, like the finalize kernel: same bits) into its LDS and
+// takes k0 / k1 from there; block 0 also writes dsum, accumulates dbeta / dgamma and zeroes `zero_other` -- the
+// OTHER slot buffer of the caller's pair, which nobody touches during this launch (the slots being read here cannot
+// be zeroed before every block has read them; the caller alternates the two buffers).
+template <bool HAS_ADD, bool FOLD>
 __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
     const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dsum, const bf16_t* __restrict__ gx_add, PadGeom g, int c8, int PY,
-    bf16_t* __restrict__ gx) {
+    bf16_t* __restrict__ gx, const float* __restrict__ slots, float* __restrict__ zero_other,
+    float* __restrict__ dsum_out, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float fold_lds[];      // [2][C] (the launch asks for 96 KB to keep a second block off the CU)
+  if (FOLD) {
+    const int C = g.C;
+    for (int j = threadIdx.x; j < 2 * C; j += 1024) {
+      const int which = j >= C ? 1 : 0, c = j - which * C;
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < kSlots; ++k) s += slots[((size_t)k * 2 + which) * C + c];
+      fold_lds[j] = s;
+      if (blockIdx.x == 0) {
+        dsum_out[j] = s;
+        if (which == 0) { if (dbeta) dbeta[c] += s; }
+        else { if (dgamma) dgamma[c] += s; }
+      }
+    }
+    if (blockIdx.x == 0)
+      for (int j = threadIdx.x; j < kSlots * 2 * C; j += 1024) zero_other[j] = 0.f;
+    __syncthreads();
+  }
   const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
   if (py >= PY) return;
   const float inv_n = 1.f / (float)g.npix;
@@ -301,8 +327,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
     rs[i] = rstd[c];
     sc[i] = gamma[c] * rs[i];
     sh[i] = beta[c] - mu[i] * sc[i];
-    k0[i] = dsum[c] * inv_n;
-    k1[i] = dsum[g.C + c] * inv_n;
+    k0[i] = (FOLD ? fold_lds[c] : dsum[c]) * inv_n;
+    k1[i] = (FOLD ? fold_lds[g.C + c] : dsum[g.C + c]) * inv_n;
   }
   auto one = [&](const u32x4_t vx, const u32x4_t vg, const u32x4_t va, int o) {
     float fx[8], fg[8], fa[8], out[8];
@@ -467,7 +493,7 @@ static int slot_target(hipStream_t st, float* scratch, int grid, size_t n, SlotT
   t->ptr = scratch; t->mask = kSlots - 1; t->det = false;
   if (!deterministic()) return NBDT_OK;
   float* rows = det_rows(st, (size_t)grid * n);
-  if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+  if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
   NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)grid * n * sizeof(float), st));
   t->ptr = rows; t->mask = ~0u; t->det = true;
   return NBDT_OK;
@@ -504,27 +530,32 @@ extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int
   return NBDT_OK;
 }
 
-// fold [rows][2][C] partial sums written by conv epilogues: block = 32 channels x 32 row lanes, every
-// thread keeps 4 independent loads in flight (a 5-block, 8-row-lane version took 39 us at 2048 rows)
+// fold [rows][2][C] partial sums written by conv epilogues: block = CL channels x (1024 / CL) row lanes, every
+// thread keeps 4 independent loads in flight (a 5-block, 8-row-lane version took 39 us at 2048 rows).
+// CL = 32: 32 row lanes (short tables).  CL = 8: 128 row lanes and four times the blocks -- a 2048-row table of a
+// 32x32x160 layer is 2.6 MB, and 5 blocks (= 5 CUs) took 14 us to pull it through their L2 ports on the forward
+// pass's critical path; 20 blocks take 6.  Same summation tree for a given (rows, CL): deterministic.
+template <int CL>
 __global__ __launch_bounds__(1024) void bn_fold_partials_kernel(const float* __restrict__ part, int rows, int C,
                                                                 float n, float eps, float momentum,
                                                                 float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var,
                                                                 float* __restrict__ save_mean,
                                                                 float* __restrict__ save_rstd) {
-  __shared__ float red[2][32][33];
-  const int cl = threadIdx.x & 31, rs = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int RL = 1024 / CL;
+  __shared__ float red[2][RL][CL + 1];
+  const int cl = threadIdx.x % CL, rs = threadIdx.x / CL;
+  const int c = blockIdx.x * CL + cl;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
   if (c < C) {
     int r = rs;
-    for (; r + 96 < rows; r += 128) {
-      s0 += part[((size_t)r * 2 + 0) * C + c];         q0 += part[((size_t)r * 2 + 1) * C + c];
-      s1 += part[((size_t)(r + 32) * 2 + 0) * C + c];  q1 += part[((size_t)(r + 32) * 2 + 1) * C + c];
-      s2 += part[((size_t)(r + 64) * 2 + 0) * C + c];  q2 += part[((size_t)(r + 64) * 2 + 1) * C + c];
-      s3 += part[((size_t)(r + 96) * 2 + 0) * C + c];  q3 += part[((size_t)(r + 96) * 2 + 1) * C + c];
+    for (; r + 3 * RL < rows; r += 4 * RL) {
+      s0 += part[((size_t)r * 2 + 0) * C + c];             q0 += part[((size_t)r * 2 + 1) * C + c];
+      s1 += part[((size_t)(r + RL) * 2 + 0) * C + c];      q1 += part[((size_t)(r + RL) * 2 + 1) * C + c];
+      s2 += part[((size_t)(r + 2 * RL) * 2 + 0) * C + c];  q2 += part[((size_t)(r + 2 * RL) * 2 + 1) * C + c];
+      s3 += part[((size_t)(r + 3 * RL) * 2 + 0) * C + c];  q3 += part[((size_t)(r + 3 * RL) * 2 + 1) * C + c];
     }
-    for (; r < rows; r += 32) {
+    for (; r < rows; r += RL) {
       s0 += part[((size_t)r * 2 + 0) * C + c];
       q0 += part[((size_t)r * 2 + 1) * C + c];
     }
@@ -534,7 +565,7 @@ __global__ __launch_bounds__(1024) void bn_fold_partials_kernel(const float* __r
   __syncthreads();
   if (rs == 0 && c < C) {
     float s = 0.f, sq = 0.f;
-    for (int k = 0; k < 32; ++k) { s += red[0][k][cl]; sq += red[1][k][cl]; }
+    for (int k = 0; k < RL; ++k) { s += red[0][k][cl]; sq += red[1][k][cl]; }
     const float mean = s / n;
     float var = sq / n - mean * mean;
     var = var > 0.f ? var : 0.f;
@@ -602,8 +633,12 @@ extern "C" int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, floa
   if (rc) return rc;
   const long long npix = (long long)B * H * W;
   const int rows = (int)((npix + 255) / 256);   // = the pixel tiles of nbdt_conv_igemm_stats
-  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partials, rows,
-                     C, (float)npix, eps, momentum, running_mean, running_var, save_mean, save_rstd);
+  if (rows >= 1024)     // tall table: four times the blocks (see the kernel header)
+    hipLaunchKernelGGL(bn_fold_partials_kernel<8>, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partials, rows,
+                       C, (float)npix, eps, momentum, running_mean, running_var, save_mean, save_rstd);
+  else
+    hipLaunchKernelGGL(bn_fold_partials_kernel<32>, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partials,
+                       rows, C, (float)npix, eps, momentum, running_mean, running_var, save_mean, save_rstd);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -704,9 +739,9 @@ extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float*
   constexpr int kForceLds = 96 * 1024;            // more than half a CU's LDS: one block per CU
   static DeviceAttr site;
   if (site.need(kForceLds)) {
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true>),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false>),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
     site.done(kForceLds);
   }
@@ -715,12 +750,13 @@ extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float*
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(blocks), blk(1024);
   if (gx_add)
-    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true>), grid, blk, kForceLds, (hipStream_t)stream, (const bf16_t*)gy,
-                       (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, (const bf16_t*)gx_add, g, c8, py,
-                       (bf16_t*)gx);
+    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, false>), grid, blk, kForceLds, (hipStream_t)stream,
+                       (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum,
+                       (const bf16_t*)gx_add, g, c8, py, (bf16_t*)gx, nullptr, nullptr, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false>), grid, blk, kForceLds, (hipStream_t)stream, (const bf16_t*)gy,
-                       (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, nullptr, g, c8, py, (bf16_t*)gx);
+    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, false>), grid, blk, kForceLds, (hipStream_t)stream,
+                       (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, nullptr, g, c8, py,
+                       (bf16_t*)gx, nullptr, nullptr, nullptr, nullptr, nullptr);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -756,6 +792,53 @@ extern "C" int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float
   rc = slot_finish(st, t, blocks, 2 * (size_t)C, scratch);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_bwd_cus(const void* gy, const void* x, const float* save_mean, const float* save_rstd,
+                               const float* gamma, const float* beta, const void* gx_add, int32_t B, int32_t H,
+                               int32_t W, int32_t C, float* slots, float* slots_other, float* dsum, float* dgamma,
+                               float* dbeta, void* gx, int32_t cus, void* stream) {
+  NBDT_REQUIRE(gy && x && save_mean && save_rstd && gamma && beta && slots && slots_other && dsum && gx, "null argument");
+  NBDT_REQUIRE(slots != slots_other, "the two slot buffers must be distinct");
+  NBDT_REQUIRE(cus >= 1 && cus <= 256, "cus must be 1..256");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const int c8 = C / 8;
+  const int py = 1024 / c8;
+  constexpr int kForceLds = 96 * 1024;
+  static DeviceAttr site;
+  if (site.need(kForceLds)) {
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    site.done(kForceLds);
+  }
+  int blocks = cus;
+  const int max_blocks = (g.npix + py - 1) / py;
+  if (blocks > max_blocks) blocks = max_blocks;
+  SlotTarget t;
+  rc = slot_target(st, slots, blocks, 2 * (size_t)C, &t);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_reduce_cus_kernel, dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, t.ptr, t.mask);
+  NBDT_LAUNCH_CHECK();
+  rc = slot_finish(st, t, blocks, 2 * (size_t)C, slots);      // (deterministic mode: the block rows -> slot 0)
+  if (rc) return rc;
+  if (gx_add)
+    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, true>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+                       (const bf16_t*)x, save_mean, save_rstd, gamma, beta, nullptr, (const bf16_t*)gx_add, g, c8, py,
+                       (bf16_t*)gx, slots, slots_other, dsum, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, true>), dim3(blocks), dim3(1024), kForceLds, st,
+                       (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, nullptr, nullptr, g, c8, py,
+                       (bf16_t*)gx, slots, slots_other, dsum, dgamma, dbeta);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

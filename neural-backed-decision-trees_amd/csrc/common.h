@@ -68,6 +68,8 @@ struct DeviceAttr {
 bool deterministic();
 // stream-ordered workspace of at least `floats` floats, one per (device, stream); nullptr if it cannot be allocated
 float* det_rows(hipStream_t st, size_t floats);
+// why the calling thread's last det_rows() returned nullptr (for the caller's error message)
+const char* det_rows_why();
 // dst[i] += rows[0][i] + rows[1][i] + ... (ascending r, one thread per i), i < n
 int det_fold(hipStream_t st, const float* rows, int nrows, size_t n, float* dst);
 

@@ -137,7 +137,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 
 #define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
   const int cin = NBDT_PIN(d.cin);
-  const int kchunks = cin >> 5;
+  const int kchunks_w = cin >> 5;            // K chunks the weight tiles were laid out for
+#ifdef NBDT_PP_KFRAC5       // timing experiment (scratch/variants): only KFRAC5/5 of the K loop -- a main loop that much faster
+  const int kchunks = kchunks_w * NBDT_PP_KFRAC5 / 5;
+#else
+  const int kchunks = kchunks_w;
+#endif
   const int nk = 9 * kchunks;
   const int a_bytes = NBDT_PIN(hg.a_bytes);
   const int a_instr = NBDT_PIN(hg.a_instr);
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     t.m0 = t.m_blk * BMH;
     t.n0 = t.n_blk * BN;
     t.base_pix = NBDT_PIN(tile_origin(d, hg, t.m_blk).base_pix);
-    t.w_tiles = w_base + (size_t)t.n_blk * kchunks * 9 * (BN * 32);
+    t.w_tiles = w_base + (size_t)t.n_blk * kchunks_w * 9 * (BN * 32);
     return t;
   };
   Tile cur = tile_of(item);

@@ -422,7 +422,7 @@ static int slot_target(hipStream_t st, float* scratch, int blocks, size_t n, Slo
   t->ptr = scratch; t->mask = kSlots - 1; t->det = false;
   if (!deterministic()) return NBDT_OK;
   float* rows = det_rows(st, (size_t)blocks * n);
-  if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+  if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
   NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)blocks * n * sizeof(float), st));
   t->ptr = rows; t->mask = ~0u; t->det = true;
   return NBDT_OK;
@@ -753,7 +753,7 @@ extern "C" int nbdt_bn_act_pool(const void* x, const float* save_mean, const flo
   const size_t n_out = (size_t)B * C;
   if (deterministic() && g.slices > 1) {
     target = det_rows(st, (size_t)g.slices * n_out);
-    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-slice rows");
+    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-slice rows", nbdt::det_rows_why());
     NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)g.slices * n_out * sizeof(float), st));
     row_stride = (long long)n_out;
   }
@@ -929,7 +929,7 @@ extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, 
   const int nrows = (int)(grid.x * grid.y);
   if (deterministic() && nrows > 1) {
     target = det_rows(st, (size_t)nrows * n_dw);
-    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
     NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)nrows * n_dw * sizeof(float), st));
     row_stride = (long long)n_dw;
   }

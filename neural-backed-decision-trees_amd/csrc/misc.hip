@@ -21,22 +21,39 @@ namespace nbdt {
 static std::atomic<int> g_deterministic{0};
 bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
 
-struct DetBuf { float* ptr = nullptr; size_t floats = 0; };
+struct DetBuf { float* ptr = nullptr; size_t floats = 0; bool captured = false; };
 static std::mutex g_det_mutex;
 static std::map<std::pair<int, hipStream_t>, DetBuf> g_det_bufs;
 
+static thread_local char g_det_why[200] = "";
+const char* det_rows_why() { return g_det_why; }
+
 float* det_rows(hipStream_t st, size_t floats) {
   int dev = 0;
+  snprintf(g_det_why, sizeof(g_det_why), "hipMalloc / hipGetDevice failed");
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(g_det_mutex);
   DetBuf& b = g_det_bufs[std::make_pair(dev, st)];
+  // hipGraph capture: hipMalloc / hipFree / hipStreamSynchronize are illegal while `st` is capturing, and a captured
+  // launch bakes this pointer in -- so inside a capture the workspace must already be large enough, and a workspace a
+  // capture has used is never freed again (a later, larger request gets a NEW buffer for eager launches only by
+  // failing loudly here: the caller releases the graph first).
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   if (b.floats < floats) {
+    if (capturing || b.captured) {
+      snprintf(g_det_why, sizeof(g_det_why), "the per-stream workspace (%zu floats) cannot grow to %zu %s: run one eager "
+               "step at the largest batch size before capturing", b.floats, floats,
+               capturing ? "inside a hipGraph capture" : "after a captured graph baked its address in");
+      return nullptr;
+    }
     // growing: the old buffer may still be read by work queued on this stream
     if (b.ptr) { if (hipStreamSynchronize(st) != hipSuccess) return nullptr; (void)hipFree(b.ptr); b.ptr = nullptr; b.floats = 0; }
     size_t want = floats < (16u << 20) ? (16u << 20) : floats + floats / 4;     // >= 64 MB, then 25 % headroom
     if (hipMalloc((void**)&b.ptr, want * sizeof(float)) != hipSuccess) { b.ptr = nullptr; return nullptr; }
     b.floats = want;
   }
+  if (capturing) b.captured = true;
   return b.ptr;
 }
 
@@ -184,7 +201,7 @@ extern "C" int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int3
   float* target = dw;
   if (deterministic()) {
     target = det_rows(st, (size_t)blocks * nout);
-    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
     NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)blocks * nout * sizeof(float), st));
   }
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), shmem, st, img,

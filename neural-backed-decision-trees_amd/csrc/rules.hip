@@ -1290,7 +1290,7 @@ static int launch_head(const nbdt_tree* t, TreeView v, const float* pooled, cons
   const size_t nw = (size_t)t->C * K, nb = (size_t)t->C;
   if (gW && deterministic()) {       // a zeroed row per block for dW and db, folded in block order afterwards
     rows = det_rows(st, (size_t)grid * (nw + nb));
-    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-block rows");
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
     NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)grid * (nw + nb) * sizeof(float), st));
     dw = rows; db = gb ? rows + (size_t)grid * nw : nullptr;
     sw = (long long)nw; sb = (long long)nb;

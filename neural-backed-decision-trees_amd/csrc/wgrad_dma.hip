@@ -281,7 +281,7 @@ static int launch_dma(WgradDmaParams& p, hipStream_t st) {
   p.dw_split_stride = 0;
   if (deterministic()) {
     float* rows = det_rows(st, (size_t)p.splits * dw_elems);
-    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-split gradients");
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-split gradients", nbdt::det_rows_why());
     NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
     p.dw = rows;
     p.dw_split_stride = (long long)dw_elems;

@@ -332,7 +332,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
   int s_end = s_begin + p.stages_per_split;
   s_end = s_end < p.stages ? s_end : p.stages;
   if (s_begin >= s_end) return;
+#ifdef NBDT_WPP_FRAC8        // timing experiment (scratch/variants): only FRAC8/8 of the stages -- a kernel that much faster
+  const int n_st = (s_end - s_begin) * NBDT_WPP_FRAC8 / 8;
+#else
   const int n_st = s_end - s_begin;
+#endif
 
 #define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
   const int g_bs = NBDT_PIN(d.g_bs), g_hs = NBDT_PIN(d.g_hs), g_ws = NBDT_PIN(d.g_ws);
@@ -493,10 +497,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
         constexpr int kk = decltype(kk_c)::value;
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
+#ifdef NBDT_WPP_GY_B128      // timing experiment: what a K-major gy image read with ds_read_b128 would cost (wrong results)
+          const int i16 = lane & 15, g16 = lane >> 4;
+          const lds_cptr a0 = ga[0] - g_lane_off[0] + ((kk * CG + (wm * WM + a) * 16 + i16) * 64 + ((g16 ^ ((i16 >> 1) & 3)) << 4));
+          gf[kk][a] = *(const __attribute__((address_space(3))) bf16x8*)a0;
+#else
           const lds_cptr a0 = ga[a & 1] + ((a >> 1) * 64 + kk * 32 * PG);
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 16 * PG));
           gf[kk][a] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#endif
         }
 #pragma unroll
         for (int t = 0; t < NTP; ++t) {
@@ -682,7 +692,7 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   p.dw_split_stride = 0;
   if (deterministic()) {
     float* rows = det_rows(st, (size_t)p.splits * dw_elems);
-    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s", "no workspace for the per-split gradients");
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-split gradients", nbdt::det_rows_why());
     NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
     p.dw = rows;
     p.dw_split_stride = (long long)dw_elems;

@@ -88,6 +88,8 @@ SIGNATURES = {
     "nbdt_bn_bwd_fold": (c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "nbdt_bn_bwd_apply_cus": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, c_int32, _P]),
     "nbdt_bn_bwd_reduce_cus": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P]),
+    "nbdt_bn_bwd_cus": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
+                                c_int32, _P]),
     "nbdt_conv_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
     "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_weight_prep_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),

@@ -233,8 +233,10 @@ class BatchNorm:
                          cus=cus)
 
     def backward_cus(self, gy, x, gx, cus, gx_add=None):
-        """Backward of relu(bn(x)) entirely on `cus` CUs: sums, fold and elementwise pass (no dgrad-epilogue partials)."""
-        ops.bn_bwd_cus(gy, x, self.mean, self.rstd, self.gamma, self.beta, self.owner.scratch(self.C), self.dsum,
+        """Backward of relu(bn(x)) entirely on `cus` CUs: sums and elementwise pass, the fold of the sums in the latter's
+        prologue (no dgrad-epilogue partials; owner.fuse_bn_fold = False: the three-launch form, A/B and tests)."""
+        scratch = self.owner.slot_pair(self.C) if self.owner.fuse_bn_fold else self.owner.scratch(self.C)
+        ops.bn_bwd_cus(gy, x, self.mean, self.rstd, self.gamma, self.beta, scratch, self.dsum,
                        self.store.g(self.name + ".weight"), self.store.g(self.name + ".bias"), gx, cus, gx_add=gx_add)
 
     def backward(self, gy, y, x, gx, relu=True, gx_add=None, g_resid=None):
@@ -262,6 +264,7 @@ class _Engine:
         self.debug_join_each_unit = False # A/B: join the side stream at the top of every unit (the schedule before round 3)
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
+        self.fuse_bn_fold = True  # CU-confined BatchNorm backward: fold of the sums inside the elementwise pass (2 launches)
         self.fuse_dw_bn_bwd = True  # MBConv: BatchNorm-backward sums in the depthwise data gradient's epilogue (A/B)
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
         self._cu_share = None     # set_cu_share(): BatchNorm-backward passes beside weight gradients on disjoint CUs
@@ -277,6 +280,18 @@ class _Engine:
             # zero on entry is the C-ABI contract; the fold kernels re-zero what they read
             self._scratch = torch.zeros(max(need, ops.BN_SLOTS * 2 * 2048), device=self.device)
         return self._scratch
+
+    def slot_pair(self, C):
+        """(slots, slots_other) for ops.bn_bwd_cus' two-launch form: two zeroed 32-slot buffers PER CHANNEL COUNT that
+        swap roles at every call (the pass leaves the one it summed into dirty and zeroes the other one -- for ITS
+        channel count, hence one pair per C).  Every user is a launch on the caller's stream, in program order."""
+        pairs = self.__dict__.setdefault("_slot_pairs", {})
+        if C not in pairs:
+            n = ops.BN_SLOTS * 2 * C
+            pairs[C] = [torch.zeros(n, device=self.device), torch.zeros(n, device=self.device), 0]
+        pair = pairs[C]
+        pair[2] ^= 1
+        return pair[pair[2]], pair[pair[2] ^ 1]
 
     def partials(self, out):
         """Workspace for the conv-epilogue BN partial sums of a padded [B,H+2,W+2,C] output."""
@@ -383,6 +398,12 @@ class _Engine:
         self._share_calibrated = True
         if self._cu_share is None:
             return self.cu_share_report
+        if ops.is_deterministic():
+            # The keep/discard decision is a TIMING measurement, and the two schedules sum the BatchNorm-backward
+            # reductions in different orders: a run-to-run different decision would break "same launches + same
+            # inputs => same bits".  Deterministic mode therefore pins the configured schedule and measures nothing.
+            self.cu_share_report = {"enabled": True, "decided_by": "deterministic mode (schedule pinned, not timed)"}
+            return self.cu_share_report
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("calibrate_cu_share() synchronises with the host: call it (or run one eager step) "
                                "before capturing the step in a hipGraph")
@@ -399,7 +420,9 @@ class _Engine:
         a2, t = self.buf(k + ".a2", B, h, w, cout), self.buf(k + ".t", B, h, w, cout)
         ga2, gt = self.buf(f"ga2_{cout}", B, h, w, cout), self.buf(f"gt_{cout}_0", B, h, w, cout)
         g = self.buf(f"g_in{cout}_{h}_0", B, h, w, cout)      # backward() rewrites all three before it reads them
-        ops.interior(g).normal_(0.0, 1e-3)                    # (plumbing: a one-off fill so the MFMAs see real data)
+        # (plumbing: a one-off fill so the MFMAs see real data -- from a private generator: the caller's global
+        # RNG stream is not advanced by a calibration)
+        ops.interior(g).normal_(0.0, 1e-3, generator=torch.Generator(device=self.device).manual_seed(0x5eed))
         split, split_us = self._share_split
         elements = B * h * w * cout
         desc, budget, n = self._share_plan(conv, a2, elements, 5 if split else 3, split_us if split else None)
@@ -432,7 +455,8 @@ class _Engine:
             dgrad(not split)
             wgrad_side(budget)
             if split:
-                ops.bn_bwd_cus(ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta, scratch, dsum, dg, db, gt, n)
+                ops.bn_bwd_cus(ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta,
+                               self.slot_pair(bn.C) if self.fuse_bn_fold else scratch, dsum, dg, db, gt, n)
             else:
                 ops.bn_bwd_fused(ga2, t, bn.mean, bn.rstd, bn.gamma, bn.beta, partials, dsum, dg, db, gt, cus=n)
             main.wait_stream(self._side)
@@ -1073,11 +1097,13 @@ class ResNetEngine(_Engine):
             comm.finish(st.grad)
 
 
-def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None, fused_head=True):
+def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None, fused_head=True,
+               zero_grad=True):
     """One full training step (main.py:233-239): zero_grad, forward, SoftTreeSupLoss fwd+bwd (one fused
     kernel -- with the classifier's forward and backward inside it when the criterion and the head's width allow,
     fused_head=False keeps linear -> loss -> linear-backward as three launches), backward, [gradient all-reduce],
-    SGD.  Returns the loss tensor (device scalar)."""
+    SGD.  Returns the loss tensor (device scalar).  zero_grad=False leaves the step's gradient in the flat gradient
+    buffer instead of having the SGD kernel clear it for the next step (tests that compare gradients)."""
     engine.zero_grad()
     names = getattr(engine, "classifier_names", None)
     if (fused_head and names is not None and hasattr(criterion, "can_fuse_head")
@@ -1093,7 +1119,7 @@ def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5
         loss, gz = criterion.loss_and_grad(z, targets)
         engine.backward(gz, comm=comm)
     scale = 1.0 / comm.world_size if comm is not None else 1.0
-    engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale, zero_grad=True)
+    engine.sgd_step(lr, momentum, weight_decay, grad_scale=scale, zero_grad=zero_grad)
     return loss
 
 

@@ -265,9 +265,17 @@ def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, 
 
 def bn_bwd_cus(gy, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx, cus, gx_add=None):
     """Whole BatchNorm(+ReLU) backward -- sums, fold, elementwise pass -- on `cus` CUs (no partials from a dgrad
-    epilogue needed): nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus."""
+    epilogue needed).  scratch: one zeroed 32-slot buffer (nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus, three
+    launches), or a PAIR (slots, slots_other) of them: nbdt_bn_bwd_cus, two launches -- the fold runs in the prologue of
+    the elementwise pass; `slots` is left dirty and `slots_other` zeroed, so the caller swaps them for the next call."""
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
+    if isinstance(scratch, (tuple, list)):
+        slots, other = scratch
+        check(lib().nbdt_bn_bwd_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(gx_add), B, H, W,
+                                    C, ptr(slots), ptr(other), ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx), int(cus),
+                                    st))
+        return
     check(lib().nbdt_bn_bwd_reduce_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, H, W, C,
                                        ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), int(cus), st))
     check(lib().nbdt_bn_bwd_apply_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dsum),

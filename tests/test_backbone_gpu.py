@@ -267,6 +267,60 @@ def test_whole_batchnorm_backward_on_a_cu_subset(B, H, W, C, with_add):
         assert ((got[3] - ref[3]).abs() <= tol).all(), cus
 
 
+@pytest.mark.parametrize("B,H,W,C", [(64, 32, 32, 160), (8, 16, 16, 320), (3, 8, 8, 640), (2, 4, 4, 32), (1, 4, 4, 2048)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_batchnorm_backward_with_the_fold_inside_the_elementwise_pass(B, H, W, C, with_add):
+    """nbdt_bn_bwd_cus (two launches: sums, then an elementwise pass whose prologue folds the 32 slots itself; a PAIR
+    of slot buffers that swap roles) against nbdt_bn_bwd_reduce_cus + nbdt_bn_bwd_apply_cus (three launches, the fold
+    in bn_bwd_finalize_kernel).  In deterministic mode both sum in the same order: gx, dsum, dgamma, dbeta bit for
+    bit.  The pair protocol: after a call the buffer it summed into is dirty and the other one is zero, so calls
+    that alternate the buffers -- here with DIFFERENT gradients -- never see each other's sums.  1, 7, 48, 256 CUs."""
+    g = torch.Generator().manual_seed(B * 13 + C)
+    def act(scale):
+        p = ops.padded(B, H, W, C, DEV)
+        ops.interior(p).copy_((torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16).to(DEV))
+        return p
+    gys, x, add = [act(1.0), act(0.5)], act(2.0), act(1.0)
+    mean, rstd = (torch.randn(C, generator=g) * 0.1).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV)
+    pair = [torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV), torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV)]
+    ops.set_deterministic(True)
+    try:
+        for cus in (1, 7, 48, 256):
+            for turn, gy in enumerate(gys):          # two calls: the buffers swap
+                outs = []
+                for fused in (False, True):
+                    dsum, dg, db = torch.empty(2 * C, device=DEV), torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+                    gx = ops.padded(B, H, W, C, DEV)
+                    sc = (pair[turn], pair[turn ^ 1]) if fused else scratch
+                    ops.bn_bwd_cus(gy, x, mean, rstd, gamma, beta, sc, dsum, dg, db, gx, cus,
+                                   gx_add=add if with_add else None)
+                    _check_border_zero(gx)
+                    outs.append((dsum, dg, db, gx))
+                assert scratch.abs().max().item() == 0
+                assert pair[turn ^ 1].abs().max().item() == 0          # left zeroed for the next call
+                assert pair[turn].abs().max().item() > 0               # holds this call's sums
+                assert outs[0][0].abs().max().item() > 0
+                for a, b in zip(outs[0], outs[1]):
+                    assert torch.equal(a, b), (cus, turn)
+    finally:
+        ops.set_deterministic(False)
+    # default mode: atomics into the 32 slots in any order -- same sums up to fp32 summation order
+    dsum_r, dg_r, db_r = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx_r = ops.padded(B, H, W, C, DEV)
+    ops.bn_bwd_cus(gys[0], x, mean, rstd, gamma, beta, scratch, dsum_r, dg_r, db_r, gx_r, 48)
+    pair[0].zero_(); pair[1].zero_()
+    dsum, dg, db = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx = ops.padded(B, H, W, C, DEV)
+    ops.bn_bwd_cus(gys[0], x, mean, rstd, gamma, beta, (pair[0], pair[1]), dsum, dg, db, gx, 48)
+    scale = dsum_r.abs().max().item()
+    for a, b in ((dsum, dsum_r), (dg, dg_r), (db, db_r)):
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-5
+    tol = 2.0 ** -7 * gx_r.float().abs() + 1e-3 * gx_r.float().abs().mean()
+    assert ((gx.float() - gx_r.float()).abs() <= tol).all()
+
+
 @pytest.mark.parametrize("B,H,W,C,expect", [(128, 32, 32, 160, {0: 250, 208: 205, 192: 190}),
                                             (256, 16, 16, 320, {0: 240, 232: 220, 176: 160}),
                                             (512, 8, 8, 640, {0: 240, 232: 160})])

@@ -649,12 +649,16 @@ def test_fused_head_step_equals_the_three_launch_step(deterministic_mode):
             eng = make()
             if hasattr(eng, "units"):
                 eng.set_cu_share(None)
-            loss = E.train_step(eng, crit, x, y, lr=0.0, momentum=0.0, weight_decay=0.0, fused_head=fused)
+            # zero_grad=False: the SGD kernel would otherwise clear the gradient buffer for the next step and the
+            # comparison below would be zeros against zeros
+            loss = E.train_step(eng, crit, x, y, lr=0.0, momentum=0.0, weight_decay=0.0, fused_head=fused,
+                                zero_grad=False)
             torch.cuda.synchronize()
             out[fused] = (loss.item(), {k: v.clone() for k, v in eng.named_params("grad").items()})
         assert out[True][0] == out[False][0]
         for name, gf in out[True][1].items():
             gu = out[False][1][name]
+            assert gu.abs().max().item() > 0.0, f"{name}: empty gradient (vacuous comparison)"
             if name in names:
                 assert (gf - gu).abs().max().item() < 2e-5 * gu.abs().max().item() + 1e-9, name
             else:

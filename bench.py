@@ -45,26 +45,38 @@ PEAK_BF16_TFLOPS = 2500.0
 GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
 
 
-TRAFFIC_FILES = ("r03_split_hbm_traffic.json", "r02_final_hbm_traffic.json")   # newest first
+TRAFFIC_FILES = ("r04_final_hbm_traffic.json", "r03_split_hbm_traffic.json", "r02_final_hbm_traffic.json")   # newest first
+LOGIT_TOLERANCE = 3e-2          # max |logit error| / logit scale against the fp32 CPU port
 
 
-def pmc_traffic():
-    """(bytes, source file): HBM-side bytes per launch of the dominant kernel family -- launch-weighted over the
+def pmc_traffic(launches_per_step):
+    """(bytes, source): HBM-side bytes per launch of the dominant kernel family -- launch-weighted over the
     forward / data-gradient kernels of the schedule this file times (plain-epilogue data gradients) -- from the
-    committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this same
-    command with --no-overlap; scratch/r03_run1.sh).  bench.py cannot collect PMC counters itself -> (None, None)
-    if absent."""
+    newest committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this
+    same command with --no-overlap; scratch/r04_traffic.sh).  bench.py cannot collect PMC counters itself, so the
+    number is only quoted when the file was recorded from THE SAME LAUNCHES: its "_meta" entry lists the implicit-GEMM
+    kernels' launches per step by device kernel name, and `launches_per_step` is what this run's roofline pass
+    counted (nbdt_debug_last_igemm after every launch).  Any difference -- a kernel renamed, added, re-routed --
+    gives (None, reason) instead of a stale number."""
     for fname in TRAFFIC_FILES:
         path = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(path):
             break
     else:
-        return None, None
+        return None, "no PMC traffic file under profiles/"
     with open(path) as f:
         t = json.load(f)
+    meta = t.pop("_meta", None)
+    if meta is None:
+        return None, f"profiles/{fname} predates the launch-count record (_meta): not quoted"
+    want = {k: round(v, 2) for k, v in meta["igemm_launches_per_step"].items()}
+    got = {k: round(v, 2) for k, v in launches_per_step.items()}
+    if want != got:
+        return None, (f"profiles/{fname} was recorded from other launches (per step, file {want} vs this run {got}): "
+                      "not quoted")
     n = b = 0
     for name, v in t.items():
-        if "conv3x3_pp_kernel" in name or "conv3x3_halo_kernel" in name or "conv_igemm_dma_kernel" in name:
+        if "conv3x3_pp_kernel" in name or "conv3x3_halo_kernel" in name or "conv_igemm_dma" in name:
             n += v["launches"]
             b += v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"])
     return (round(b / n) if n else None), "profiles/" + fname
@@ -106,9 +118,11 @@ def agreement(eng, num_classes, n, dev):
     hard = _C.hard_forward(tree.device_handle(dev.index), torch.from_numpy(z).to(dev), want_onehot=False)[0]
     hard_ref = O.hard_forward(otree, z_ref)
     scale = float(np.abs(z_ref).max())
+    err = float(np.abs(z - z_ref).max()) / scale
     return {"argmax": round(float((z.argmax(1) == z_ref.argmax(1)).mean()), 4),
             "hard_pred": round(float((hard.cpu().numpy() == hard_ref).mean()), 4), "n": n,
-            "max_abs_logit_err_over_scale": round(float(np.abs(z - z_ref).max()) / scale, 5),
+            "max_abs_logit_err_over_scale": round(err, 5), "tolerance": LOGIT_TOLERANCE,
+            "within_tolerance": bool(err < LOGIT_TOLERANCE),
             "vs": "fp32 torch-CPU port of WRN-28-10 (oracle/torch_models.py) with the engine's trained weights and "
                   "running statistics, eval mode; the reference itself needs pytorchcv (absent) for this backbone"}
 
@@ -147,6 +161,93 @@ def cpu_baseline(batch, num_classes, steps=3):
                       "pytorchcv and /root/reference does not exist on the GPU box"}
 
 
+# algorithmic GFLOP per image of a training step (forward 2*MAC of the REAL channel counts, x3 for the two gradients);
+# ResNet18 (reference nbdt/models/resnet.py:115-149, 3x3 stem, no max-pool): 555.4 MMAC at 32x32, x4 at 64x64
+GFLOP_RESNET18_32 = 3 * 2 * 0.5554
+GFLOP_RESNET18_64 = 4 * GFLOP_RESNET18_32
+
+
+def other_configs(dev, budget_s=0.6):
+    """The other BASELINE.json configurations on this GPU, each a <= ~1 s measurement of nbdt.engine.train_step (or the
+    eval-mode forward + HardNBDT rules) on one resident synthetic batch: C1 ResNet18/CIFAR10 B=128, C3's per-GPU shard
+    (WRN-28-10/CIFAR100, 1024 images over 4 GPUs = 256), C4 ResNet18/TinyImagenet200 64x64 B=128 (SoftTreeSupLoss with
+    tree-supervision weight 10, and HardNBDT inference), C5 EfficientNet-B0/Imagenet1000 224x224 B=128.  `frac` is
+    against the bound named: bf16 MFMA peak for the ResNets (algorithmic flops of the real channel counts), HBM peak
+    for EfficientNet-B0 with a LOWER BOUND on the bytes (every resident activation / gradient buffer written once and
+    read once per step; buffers re-used between units are counted once).  `profile`: the committed
+    rocprofv3 --kernel-trace --stats summary of the same configuration (scratch/run_config.py <name> --one-stream)."""
+    from nbdt import engine as E
+    from nbdt.engine_effnet import EfficientNetEngine
+    from nbdt.loss import SoftTreeSupLoss
+    from nbdt.model import HardEmbeddedDecisionRules
+    from nbdt.tree import Tree
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        one = time.perf_counter() - t0
+        steps = max(3, min(40, int(budget_s / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, steps
+
+    def entry(name, B, dt, steps, gflop_img=None, bytes_step=None, profile=None, mode="train step"):
+        e = {"config": name, "mode": mode, "batch_per_gpu": B, "value": round(B / dt, 1), "unit": "images/sec",
+             "ms_per_step": round(1e3 * dt, 3), "steps": steps}
+        if gflop_img is not None:
+            tf = B / dt * gflop_img / 1e3
+            e.update({"bound": "mfma", "gflop_per_image": round(gflop_img, 3), "achieved": round(tf, 1),
+                      "peak": PEAK_BF16_TFLOPS, "peak_unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)})
+        if bytes_step is not None:
+            gbs = bytes_step / dt / 1e9
+            e.update({"bound": "hbm", "bytes_per_step_lower_bound": int(bytes_step), "achieved": round(gbs, 1),
+                      "peak": 8000.0, "peak_unit": "GB/s", "frac": round(gbs / 8000.0, 4)})
+        if profile:
+            e["profile"] = profile
+        return e
+
+    def train_case(name, eng, dataset, hierarchy, B, size, C, tsw, **kw):
+        crit = SoftTreeSupLoss(dataset=dataset, criterion=nn.CrossEntropyLoss(), hierarchy=hierarchy,
+                               tree_supervision_weight=tsw)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(B, 3, size, size, generator=g).to(dev)
+        y = torch.randint(0, C, (B,), generator=g).to(dev)
+        dt, steps = timeit(lambda: E.train_step(eng, crit, x, y, 0.01))
+        if kw.pop("resident_bytes", False):
+            kw["bytes_step"] = 2 * sum(t.numel() * t.element_size() for t in eng._bufs.values())
+        return entry(name, B, dt, steps, **kw)
+
+    out = []
+    out.append(train_case("C1 ResNet18 + SoftTreeSupLoss, CIFAR10 (10 leaves)", E.ResNetEngine(10, device=dev),
+                          "CIFAR10", "induced-ResNet18", 128, 32, 10, 1.0, gflop_img=GFLOP_RESNET18_32,
+                          profile="profiles/r04_c1_kernel_stats_one_stream.txt"))
+    out.append(train_case("C3 WideResNet28x10 + SoftTreeSupLoss, CIFAR100 (100 leaves): one GPU's 256-image share of "
+                          "batch 1024 on 4 GPUs", E.WRNEngine(100, device=dev), "CIFAR100",
+                          "induced-wrn28_10_cifar100", 256, 32, 100, 1.0, gflop_img=GFLOP_PER_IMG_TRAIN,
+                          profile="profiles/r04_c3_kernel_stats_one_stream.txt"))
+    eng = E.ResNetEngine(200, device=dev)
+    out.append(train_case("C4 ResNet18 + SoftTreeSupLoss (tree-supervision weight 10), TinyImagenet200 64x64 (200 "
+                          "leaves)", eng, "TinyImagenet200", "induced-ResNet18", 128, 64, 200, 10.0,
+                          gflop_img=GFLOP_RESNET18_64, profile="profiles/r04_c4_kernel_stats_one_stream.txt"))
+    rules = HardEmbeddedDecisionRules(tree=Tree("TinyImagenet200", hierarchy="induced-ResNet18"))
+    x = torch.randn(128, 3, 64, 64, device=dev)
+    dt, steps = timeit(lambda: rules.predict(eng.forward(x, training=False)))
+    out.append(entry("C4 ResNet18 + HardNBDT (argmax path), TinyImagenet200 64x64", 128, dt, steps,
+                     gflop_img=GFLOP_RESNET18_64 / 3, profile="profiles/r04_c4inf_kernel_stats_one_stream.txt",
+                     mode="inference: eval-mode backbone + hard decision rules"))
+    del eng
+    out.append(train_case("C5 EfficientNet-B0 + SoftTreeSupLoss, Imagenet1000 induced hierarchy (1000 leaves), 224x224",
+                          EfficientNetEngine(1000, device=dev), "Imagenet1000", "induced-efficientnet_b7b", 128, 224,
+                          1000, 1.0, resident_bytes=True, profile="profiles/r04_c5_kernel_stats_one_stream.txt"))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +271,8 @@ def main():
                          "tensors, so `--gpus 2 --backend gloo --share-gpu` runs the N-rank branch on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (tests on a 1-GPU box)")
     ap.add_argument("--agreement-n", type=int, default=512, help="images in the prediction-agreement check (0: skip)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the <= 1 s measurements of the other BASELINE.json configurations (`other_configs`)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -292,7 +395,7 @@ def main():
                        "allreduce_ms_exposed": round(ms - 1e3 * dt_nocomm, 3)}
     if timer is not None:
         summ = timer.summary()
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic({k: v / roof_steps for k, v in timer.kernels.items()})
         k = summ.get("conv_igemm")
         if k:
             out["roofline"] = {"bound": "mfma",
@@ -330,8 +433,14 @@ def main():
             out["step_ms_in_mfma_kernels"] = round((k["ms"] + w["ms"]) / roof_steps, 3) if k else None
     if world == 1 and args.agreement_n > 0:
         out["agreement"] = agreement(eng, args.classes, args.agreement_n, dev)
+    if world == 1 and not args.no_other_configs:
+        del eng      # (its 7 GB of activations; everything that reads it has run)
+        out["other_configs"] = other_configs(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.classes)
+    if world == 1 and "agreement" in out and not out["agreement"]["within_tolerance"]:
+        print(f"bench.py: logit error {out['agreement']['max_abs_logit_err_over_scale']} of the logit scale exceeds the "
+              f"stated tolerance {LOGIT_TOLERANCE}", file=sys.stderr)
     print(json.dumps(out))
 
 

@@ -16,11 +16,14 @@ recipes in the reference's ``scripts/*.sh`` keep their arguments.  What differs,
   dict with ``train_x [N,3,H,W]`` uint8|float, ``train_y``, ``test_x``, ``test_y``; already
   normalised if float, scaled to [0,1] and normalised with the reference's CIFAR statistics if uint8)
   or from ``--synthetic N`` (CIFAR-shaped noise with a learnable class signal, for smoke runs).
-* ``--analysis SoftEmbeddedDecisionRules | HardEmbeddedDecisionRules`` reports the accuracy of the decision
-  rules applied to the backbone's logits (what the reference's analyzers of those names print, reference
-  nbdt/analysis.py:224-229) next to the backbone's `--metric` during evaluation.  The reference's analyzer hook
-  protocol and its presentation analyzers are out of scope: the two statistics
-  are counted here, on the device, one host transfer per evaluation.
+* ``--analysis Noop | SoftEmbeddedDecisionRules | HardEmbeddedDecisionRules`` drives an analyzer of ``nbdt.analysis``
+  through the reference's hook protocol (reference main.py:212-288, nbdt/analysis.py:81-130): ``epoch_context`` around
+  every epoch, ``start_train`` / ``end_train`` around the training pass, ``start_test`` / ``update_batch(logits,
+  targets, images)`` per evaluation batch / ``end_test``.  The two rules analyzers report the accuracy of the decision
+  rules applied to the backbone's logits (reference nbdt/analysis.py:204-252) next to the backbone's ``--metric``; their
+  counters stay on the device, one host transfer per evaluation.  The training pass does not call ``update_batch``: the
+  fused step (classifier + rules + loss + their backward in one launch) never materialises the logits.  The
+  reference's presentation analyzers are out of scope.
 """
 import argparse
 import math
@@ -33,16 +36,16 @@ import torch.nn as nn
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+from nbdt import analysis  # noqa: E402
 from nbdt import dist as ndist  # noqa: E402
 from nbdt import loss as losses  # noqa: E402
 from nbdt import models  # noqa: E402
 from nbdt.engine import train_step  # noqa: E402
-from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules, coerce_state_dict  # noqa: E402
+from nbdt.model import coerce_state_dict  # noqa: E402
 from nbdt.tree import Tree  # noqa: E402
 from nbdt.utils import DATASET_TO_NUM_CLASSES, DATASETS  # noqa: E402
 
 CIFAR_MEAN, CIFAR_STD = (0.4914, 0.4822, 0.4465), (0.2023, 0.1994, 0.2010)   # reference nbdt/data/cifar.py:17-19
-ANALYSES = {"HardEmbeddedDecisionRules": HardEmbeddedDecisionRules, "SoftEmbeddedDecisionRules": SoftEmbeddedDecisionRules}
 METRICS = {"top1": 1, "top2": 2, "top5": 5, "top10": 10}      # the reference's --metric names -> k
 
 
@@ -81,7 +84,7 @@ def build_parser():
     p.add_argument("--eval", action="store_true")
     p.add_argument("--loss", choices=losses.names, default=["CrossEntropyLoss"], nargs="+")
     p.add_argument("--metric", choices=sorted(METRICS), default="top1")
-    p.add_argument("--analysis", choices=sorted(ANALYSES))
+    p.add_argument("--analysis", choices=analysis.names, help="analyzer run during every evaluation (nbdt.analysis)")
     # nbdt/tree.py:26-35
     p.add_argument("--hierarchy")
     p.add_argument("--path-graph")
@@ -202,11 +205,11 @@ def load_data(args, num_classes, device):
     return [*make(n), *make(max(n // 4, args.batch_size))]
 
 
-def evaluate(net, criterion_module, rules, k, x, y, batch, device):
-    """reference main.py:262-277: top-k accuracy of the backbone's logits, accuracy of the decision rules on the
-    same logits (None without --analysis) and the mean loss over (x, y)."""
+def evaluate(net, criterion_module, analyzer, k, x, y, batch, device):
+    """reference main.py:262-277: top-k accuracy of the backbone's logits and the mean loss over (x, y); every batch's
+    logits also go to the analyzer (update_batch), which keeps its own statistic."""
     net.eval()
-    plain, nbdt = HitCounter(k, device), HitCounter(1, device)
+    plain = HitCounter(k, device)
     loss_sum = torch.zeros((), device=device)
     batches = 0
     with torch.no_grad():
@@ -216,9 +219,8 @@ def evaluate(net, criterion_module, rules, k, x, y, batch, device):
             loss_sum += criterion_module(z, yb)
             batches += 1
             plain.add(z, yb)
-            if rules is not None:
-                nbdt.add(rules(z), yb)
-    return plain.percent(), (nbdt.percent() if rules is not None else None), float(loss_sum) / max(batches, 1)
+            analyzer.update_batch(z, yb, xb)
+    return plain.percent(), float(loss_sum) / max(batches, 1)
 
 
 def main(argv=None):
@@ -275,12 +277,13 @@ def main(argv=None):
 
     criterion = build_criterion(args, tree, net=net, checkpoint_path=checkpoint_path)
     fast = criterion if hasattr(criterion, "loss_and_grad") else _PlainCE(tree)
-    rules = ANALYSES[args.analysis](tree=tree) if args.analysis else None
-    rules_name = {"HardEmbeddedDecisionRules": "NBDT-Hard", "SoftEmbeddedDecisionRules": "NBDT-Soft"}.get(args.analysis)
-    best_nbdt = 0.0
+    analyzer_cls = getattr(analysis, args.analysis or "Noop")
+    analyzer = analyzer_cls(tree=tree, metric=args.metric) if args.analysis not in (None, "Noop") else analyzer_cls(tree.classes)
+    analyzer.verbose = rank == 0                  # one rank prints
     comm = ndist.GradComm() if world > 1 else None
     per_rank = args.batch_size // world
 
+    @analyzer.train_function
     def train(epoch):
         if hasattr(criterion, "set_epoch"):
             criterion.set_epoch(epoch, args.epochs)
@@ -299,13 +302,13 @@ def main(argv=None):
         log("Loss: %.3f (%d steps of %d x %d images)" % (total.item() / max(steps, 1), steps, world, per_rank))
 
     def test(epoch, checkpoint=True):
-        nonlocal best_acc, best_nbdt
-        acc, nbdt_acc, loss = evaluate(net, criterion, rules, METRICS[args.metric], test_x, test_y, 100, device)
-        extra = ""
-        if nbdt_acc is not None:
-            best_nbdt = max(best_nbdt, nbdt_acc)
-            extra = f" | {rules_name}: {nbdt_acc:.3f}% (best {best_nbdt:.3f}%)"
+        nonlocal best_acc
+        analyzer.start_test(epoch)
+        acc, loss = evaluate(net, criterion, analyzer, METRICS[args.metric], test_x, test_y, 100, device)
+        nbdt_acc = analyzer.accuracy() if hasattr(analyzer, "accuracy") else None
+        extra = f" | {analyzer.name}: {nbdt_acc:.3f}%" if nbdt_acc is not None else ""
         log("Loss: %.3f | Acc: %.3f%%%s" % (loss, acc, extra))
+        analyzer.end_test(epoch)
         log(f"Accuracy: {acc} | Best Accuracy: {best_acc}")
         if acc > best_acc and checkpoint and rank == 0:
             log(f"Saving to {checkpoint_fname} ({acc})..")
@@ -318,11 +321,13 @@ def main(argv=None):
     if args.eval:
         if not args.resume:
             log(" * Warning: Model is not loaded from checkpoint. Use --resume")
-        return test(0, checkpoint=False)
+        with analyzer.epoch_context(0):
+            return test(0, checkpoint=False)
     result = None
     for epoch in range(start_epoch, args.epochs):
-        train(epoch)
-        result = test(epoch)
+        with analyzer.epoch_context(epoch):
+            train(epoch)
+            result = test(epoch)
     return result
 
 

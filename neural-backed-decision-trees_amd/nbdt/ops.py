@@ -164,6 +164,7 @@ class KernelTimer:
     def __init__(self, only=None):
         self.items = []   # (kind, flops, start_event, end_event)
         self.only = only  # restrict to these kinds (None: all)
+        self.kernels = {}  # device kernel name (nbdt_debug_last_igemm / _wgrad) -> launches bracketed
 
     def wants(self, kind):
         return self.only is None or kind in self.only
@@ -173,6 +174,9 @@ class KernelTimer:
         e = torch.cuda.Event(enable_timing=True)
         self.items.append((kind, flops, s, e))
         return s, e
+
+    def count(self, kernel_name):
+        self.kernels[kernel_name] = self.kernels.get(kernel_name, 0) + 1
 
     def summary(self):
         torch.cuda.synchronize()
@@ -214,6 +218,7 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
                                           ptr(bn_scratch), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
+        _timer.count(last_igemm_kernel())
 
 
 def conv_igemm_multi(descs, inp, w_bf16, out):
@@ -227,6 +232,7 @@ def conv_igemm_multi(descs, inp, w_bf16, out):
     check(lib().nbdt_conv_igemm_multi(arr, len(descs), ptr(inp), ptr(w_bf16), ptr(out), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
+        _timer.count(last_igemm_kernel())
 
 
 def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, partials):
@@ -240,6 +246,7 @@ def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, part
                                       ptr(rstd), ptr(gamma), ptr(beta), ptr(partials), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
+        _timer.count(last_igemm_kernel())
 
 
 def conv_igemm_affine(desc, inp, w_bf16, out, scale, shift, act=1, residual=None):

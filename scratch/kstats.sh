@@ -3,7 +3,7 @@
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for V in "$@"; do
   if [ "$V" = base ]; then L=""; else L="NBDT_HIP_LIB=$R/scratch/variants/libnbdt_$V.so"; fi
-  env $L rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$V -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-overlap > /tmp/ks_$V.log 2>&1
+  env $L rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$V -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-other-configs --agreement-n 0 --no-overlap > /tmp/ks_$V.log 2>&1
   echo "== $V"; python - <<PY
 import csv,glob
 f=glob.glob('/tmp/ks_$V/**/*kernel_stats.csv',recursive=True)[0]

@@ -1,8 +1,11 @@
 """Per-kernel HBM-side traffic from the two PMC passes of scratch/prof_bench.sh.
-usage: python scratch/traffic_report.py gpurun_out/prof_bench_<tag> profiles/<prefix>
-writes <prefix>_hbm_traffic.txt / .json (bytes per launch; FETCH_SIZE/WRITE_SIZE are reported in KB)."""
-import collections, csv, json, sys
+usage: python scratch/traffic_report.py gpurun_out/prof_bench_<tag> profiles/<prefix> [steps profiled]
+writes <prefix>_hbm_traffic.txt / .json (bytes per launch; FETCH_SIZE/WRITE_SIZE are reported in KB).  With the number
+of profiled steps the json also gets a "_meta" entry: the implicit-GEMM kernels' launches per step by device kernel
+name -- bench.py quotes the file for `roofline.traffic` only if its own run launches the same kernels as often."""
+import collections, csv, json, re, sys
 src, prefix = sys.argv[1], sys.argv[2]
+steps = float(sys.argv[3]) if len(sys.argv) > 3 else None
 
 
 def load(path, counter):
@@ -31,6 +34,15 @@ with open(prefix + "_hbm_traffic.txt", "w") as fo:
              "counts Infinity-Cache hits\n\n")
     for _, k, n, f, w in rows:
         fo.write(f"{k[:70]:70s} n={n:4d} FETCH {f/1e6:8.1f} MB (x2: {2*f/1e6:8.1f})  WRITE {w/1e6:8.1f} MB\n")
+if steps:
+    per_step = collections.defaultdict(float)
+    for k, v in out.items():
+        fam = re.sub(r"<.*", "", k.replace("void ", ""))
+        if fam in ("conv3x3_pp_kernel", "conv3x3_halo_kernel", "conv_igemm_dma_kernel", "conv_igemm_dma_multi_kernel"):
+            if fam == "conv3x3_pp_kernel" and re.search(r", 4>$", k):
+                fam = "conv3x3_pp_kernel/4w"          # the name nbdt_debug_last_igemm reports for the 4-wave form
+            per_step[fam] += v["launches"] / steps
+    out["_meta"] = {"steps_profiled": steps, "igemm_launches_per_step": dict(per_step)}
 with open(prefix + "_hbm_traffic.json", "w") as fo:
     json.dump(out, fo, indent=1)
 print(open(prefix + "_hbm_traffic.txt").read()[:1800])

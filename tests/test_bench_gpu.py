@@ -31,6 +31,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+    # `roofline.traffic` is quoted from a committed PMC file only if this run launched the same kernels as often
+    # (this 64-image run does not: other tile counts pick other kernels) -- otherwise null with the reason
+    assert r["traffic"] is None and "not quoted" in r["traffic_source"]
+    # "top-1 vs ref": the logit error of the trained weights against the fp32 CPU port stays inside DESIGN.md's tolerance
+    a = d["agreement"]
+    assert a["tolerance"] == 3e-2 and a["within_tolerance"] and a["max_abs_logit_err_over_scale"] < a["tolerance"]
+    # the other BASELINE.json configurations, each with its bound and fraction
+    oc = d["other_configs"]
+    assert [o["config"][:2] for o in oc] == ["C1", "C3", "C4", "C4", "C5"]
+    for o in oc:
+        assert o["value"] > 0 and o["unit"] == "images/sec" and o["bound"] in ("mfma", "hbm") and 0 < o["frac"] < 1
+        assert abs(o["value"] - o["batch_per_gpu"] / (o["ms_per_step"] * 1e-3)) < 0.02 * o["value"]
+        assert abs(o["frac"] - o["achieved"] / o["peak"]) < 1e-3
+        assert os.path.exists(os.path.join(ROOT, o["profile"])), o["profile"]
 
 
 def test_bench_two_rank_branch_runs_on_one_gpu_over_gloo():

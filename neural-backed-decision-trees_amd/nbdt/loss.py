@@ -76,58 +76,48 @@ class TreeSupLoss(nn.Module):
                  tree_supervision_weight_power=1, xent_weight=1, xent_weight_end=None,
                  xent_weight_power=1):
         super().__init__()
-        if not tree:
-            tree = Tree(dataset, path_graph, path_wnids, classes, hierarchy=hierarchy)
-        self.num_classes = len(tree.classes)
-        self.tree = tree
-        self.rules = Rules(tree=tree)
-        self.tree_supervision_weight = tree_supervision_weight
-        self.tree_supervision_weight_end = (
-            tree_supervision_weight_end if tree_supervision_weight_end is not None
-            else tree_supervision_weight)
-        self.tree_supervision_weight_power = tree_supervision_weight_power
-        self.xent_weight = xent_weight
-        self.xent_weight_end = xent_weight_end if xent_weight_end is not None else xent_weight
-        self.xent_weight_power = xent_weight_power
+        self.tree = tree or Tree(dataset, path_graph, path_wnids, classes, hierarchy=hierarchy)
+        self.num_classes = len(self.tree.classes)
+        self.rules = Rules(tree=self.tree)
         self.criterion = criterion
-        self.progress = 1
-        self.epochs = 0
+        # two weight schedules, each (value at epoch 0, value at the last epoch, exponent of the progress); the public
+        # attribute names are the reference's (a driver may read or set them between epochs)
+        for prefix, first, last, power in (("tree_supervision_weight", tree_supervision_weight,
+                                            tree_supervision_weight_end, tree_supervision_weight_power),
+                                           ("xent_weight", xent_weight, xent_weight_end, xent_weight_power)):
+            setattr(self, prefix, first)
+            setattr(self, prefix + "_end", first if last is None else last)
+            setattr(self, prefix + "_power", power)
+        self.epochs, self.progress = 0, 1       # progress 1: the *_end weights, until set_epoch() starts a schedule
 
     @staticmethod
     def assert_output_not_nbdt(outputs):
-        assert getattr(outputs, "_nbdt_output_flag", False) is False, (
-            "Uh oh! Looks like you passed an NBDT model's output to an NBDT "
-            "loss. NBDT losses are designed to take in the *original* model's "
-            "outputs, as input. NBDT models are designed to only be used "
-            "during validation and inference, not during training. Confused? "
-            " Check out github.com/alvinwan/nbdt#convert-neural-networks-to-decision-trees"
-            " for examples and instructions.")
+        if getattr(outputs, "_nbdt_output_flag", False):
+            raise AssertionError(
+                "these logits came out of an NBDT wrapper (SoftNBDT / HardNBDT): a tree-supervision loss is computed on "
+                "the plain backbone's outputs -- the NBDT wrappers are for validation and inference only")
 
     def forward_tree(self, outputs, targets):
         raise NotImplementedError()
 
     def get_weight(self, start, end, power=1):
-        progress = self.progress ** power
-        return (1 - progress) * start + progress * end
+        """start -> end along progress ** power (reference nbdt/loss.py:191-193)."""
+        t = self.progress ** power
+        return start + (end - start) * t if t not in (0, 1) else (end if t == 1 else start)
 
     def current_weights(self):
-        """(xent_weight, tree_weight) at the current epoch progress (reference :195-202)."""
-        tree_weight = self.get_weight(self.tree_supervision_weight, self.tree_supervision_weight_end,
-                                      self.tree_supervision_weight_power)
-        xent_weight = self.get_weight(self.xent_weight, self.xent_weight_end, self.xent_weight_power)
-        return xent_weight, tree_weight
+        """(cross-entropy weight, tree-supervision weight) at the current epoch progress -- the only place the two
+        schedules are evaluated (forward(), the fused loss kernels and GraphedStep all ask here)."""
+        return (self.get_weight(self.xent_weight, self.xent_weight_end, self.xent_weight_power),
+                self.get_weight(self.tree_supervision_weight, self.tree_supervision_weight_end,
+                                self.tree_supervision_weight_power))
 
     def forward(self, outputs, targets):
-        loss_xent = self.criterion(outputs, targets)
-        loss_tree = self.forward_tree(outputs, targets)
-        xent_weight, tree_weight = self.current_weights()
-        return loss_xent * xent_weight + loss_tree * tree_weight
+        w_xent, w_tree = self.current_weights()
+        return self.criterion(outputs, targets) * w_xent + self.forward_tree(outputs, targets) * w_tree
 
     def set_epoch(self, cur, total):
-        self.epochs = cur
-        self.progress = cur / total
-        if hasattr(super(), "set_epoch"):
-            super().set_epoch(cur, total)
+        self.epochs, self.progress = cur, cur / total
 
 
 class SoftTreeSupLoss(TreeSupLoss):

@@ -393,6 +393,7 @@ def main():
                        "allreduce_bytes_per_rank": int(eng.store.grad.numel()) * 4, "buckets": 3,
                        "ms_per_step_without_allreduce": round(1e3 * dt_nocomm, 3),
                        "allreduce_ms_exposed": round(ms - 1e3 * dt_nocomm, 3)}
+        out["comm"].update(comm.describe(int(eng.store.grad.numel()) * 4))
     if timer is not None:
         summ = timer.summary()
         traffic, traffic_src = pmc_traffic({k: v / roof_steps for k, v in timer.kernels.items()})

@@ -66,6 +66,15 @@ int nbdt_version(void);
  * nbdt_se_gate_bwd's parameter gradients) -- and the rules layer, which has no atomics. */
 int nbdt_set_deterministic(int32_t on);
 int nbdt_get_deterministic(void);
+/* CUs (0..128, process-wide, default 0) the one-block-per-CU MFMA kernels leave free: the persistent forward / data-
+ * gradient kernel launches 8 x (32 - ceil(n / 8)) blocks instead of 256 and the weight gradient is sized for at most
+ * 256 - n.  For data-parallel training: RCCL's all-reduce kernels (one block per channel, NCCL_MAX_NCHANNELS of them)
+ * run beside the backward pass, and a persistent block that finds its CU held by one of them starts when that block
+ * ends -- the whole launch then waits for it (measured with a look-alike holder kernel: up to +1.7 ms per step).  The
+ * engine sets n = the channel count while gradient buckets are in flight and 0 otherwise.  Results do not change
+ * (same tiles, other block -> tile assignment).  Replaces nothing in the reference (DataParallel, main.py:160-162). */
+int nbdt_set_reserved_cus(int32_t n);
+int nbdt_get_reserved_cus(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int nbdt_device_count(void);
 
@@ -388,6 +397,38 @@ int nbdt_se_gate_bwd(const float* dgate, const float* gate, const float* pre1, c
 int nbdt_dropout_fwd(const float* x, int64_t n, float p, uint32_t seed, uint8_t* mask, float* y,
                      void* stream);
 int nbdt_dropout_bwd(const float* gy, int64_t n, float p, const uint8_t* mask, float* gx, void* stream);
+
+/* ------------------------------------------------------------------ verification-only fp32-storage kernels
+ * NOT the product path (csrc/ref_fp32.hip): the same operators as above on fp32 padded NHWC tensors, written to be
+ * obviously right (one thread per output, plain loops, double accumulators), taking the SAME descriptors.  The engines'
+ * fp32 reference mode (engine.set_reference_fp32) routes every launch here while keeping its launch order, streams,
+ * events and buffer rotation, so that ONE test can show the whole training step -- in the shipped schedule -- agreeing
+ * with the fp32 oracle to 1e-5 instead of the cosine ~0.9 that bf16 storage allows (tests/test_reference_fp32_gpu.py).
+ * They replace, for verification, the same reference lines as their product twins (nbdt/models/resnet.py:47-74,
+ * 115-149; pytorchcv PreResUnit). */
+int nbdt_ref_conv(const nbdt_conv_desc* d, const float* in, const float* w, float* out, const float* residual,
+                  void* stream);
+int nbdt_ref_wgrad(const nbdt_wgrad_desc* d, const float* x, const float* gy, float* dw, void* stream);
+/* partials == NULL: nbdt_bn_stats.  partials != NULL: the conv-epilogue form -- row 0 of bn_partials[rows][2][C]
+ * receives sum / sum of squares, the other rows zero (nbdt_bn_finalize folds them as usual). */
+int nbdt_ref_bn_stats(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
+                      float* running_mean, float* running_var, float* save_mean, float* save_rstd, float* partials,
+                      void* stream);
+int nbdt_ref_bn_apply(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                      const float* beta, const float* residual, int32_t relu, int32_t B, int32_t H, int32_t W,
+                      int32_t C, float* y, void* stream);
+/* nbdt_bn_bwd_reduce + nbdt_bn_bwd_apply (gy given) or nbdt_pool_bn_bwd_reduce + _apply (gy NULL, gpooled given);
+ * reduce == 0: the elementwise pass only, with the caller's dsum */
+int nbdt_ref_bn_bwd(const float* gy, const float* gpooled, const float* y, const float* x, const float* save_mean,
+                    const float* save_rstd, const float* gamma, const float* beta, int32_t relu, const float* gx_add,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t reduce, float* dsum, float* dgamma,
+                    float* dbeta, float* gx, float* g_resid, void* stream);
+int nbdt_ref_bn_relu_pool(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                          const float* beta, int32_t B, int32_t H, int32_t W, int32_t C, float* pooled, void* stream);
+int nbdt_ref_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32_t W, int32_t cout_real,
+                       int32_t cpad, int32_t stride, float* out, void* stream);
+int nbdt_ref_stem_wgrad(const float* img, const float* gy, int32_t B, int32_t H, int32_t W, int32_t cout_real,
+                        int32_t cpad, int32_t stride, float* dw, void* stream);
 
 /* ------------------------------------------------------------------ stem / head / optimizer */
 /* stem Conv2d(3->cout_real, 3x3, pad 1, stride 1|2) on NCHW fp32 images [B,3,H,W] -> padded NHWC

@@ -66,6 +66,9 @@ struct DeviceAttr {
 // epilogue), whose order changes from run to run.  With the switch on, each of them adds into a zeroed library-owned
 // row per block / per pixel split instead -- one add per address -- and det_fold() sums the rows in index order.
 bool deterministic();
+// CUs the one-block-per-CU MFMA kernels leave free (nbdt_set_reserved_cus): a collective's kernels (RCCL, one block per
+// channel) running beside the backward pass get them, instead of making persistent blocks wait for a CU they hold
+int reserved_cus();
 // stream-ordered workspace of at least `floats` floats, one per (device, stream); nullptr if it cannot be allocated
 float* det_rows(hipStream_t st, size_t floats);
 // why the calling thread's last det_rows() returned nullptr (for the caller's error message)

@@ -684,7 +684,9 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
       p.overlap = 1;
       if (shmem < need) shmem = need;
     }
-    per_round = std::min(p.per_xcd, 32);     // 32 CUs per XCD
+    // 32 CUs per XCD, minus the ones reserved for a collective's kernels (nbdt_set_reserved_cus, spread over the XCDs):
+    // a persistent block that found its CU held by an RCCL block would start when that block ends, a millisecond late
+    per_round = std::min(p.per_xcd, std::max(1, 32 - (reserved_cus() + 7) / 8));
 #ifdef NBDT_PP_NO_PERSIST                    // timing experiment: one block per item, packed epilogue LDS
     per_round = p.per_xcd;
     p.overlap = 0;

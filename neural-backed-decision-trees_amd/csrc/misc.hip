@@ -79,6 +79,17 @@ extern "C" int nbdt_set_deterministic(int32_t on) {
 }
 extern "C" int nbdt_get_deterministic(void) { return nbdt::deterministic() ? 1 : 0; }
 
+namespace nbdt {
+static std::atomic<int> g_reserved_cus{0};
+int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
+}  // namespace nbdt
+extern "C" int nbdt_set_reserved_cus(int32_t n) {
+  NBDT_REQUIRE(n >= 0 && n <= 128, "reserved CUs must be 0..128");
+  nbdt::g_reserved_cus.store(n, std::memory_order_relaxed);
+  return NBDT_OK;
+}
+extern "C" int nbdt_get_reserved_cus(void) { return nbdt::reserved_cus(); }
+
 // ------------------------------------------------------------------------------------------ stem
 // thread = (pixel, 8-cout chunk); weights [cout][3][3][3] (co, r, s, ci) staged in LDS
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w,

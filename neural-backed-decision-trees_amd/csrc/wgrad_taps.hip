@@ -15,6 +15,7 @@
 // Partial sums over the pixel splits are combined with fp32 atomics into dw (+= semantics).
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 using namespace nbdt;
@@ -660,7 +661,8 @@ static void split_items(WgradTapsParams& p, int wm, bool pp) {
   const nbdt_wgrad_desc& d = p.d;
   p.n_ci_blocks = d.cin / 32;
   const int tiles = (d.cout / (32 * wm)) * p.n_ci_blocks;
-  const int cus = d.cu_budget > 0 ? d.cu_budget : 256;
+  int cus = d.cu_budget > 0 ? d.cu_budget : 256;
+  cus = std::max(8, std::min(cus, 256 - reserved_cus()));      // (nbdt_set_reserved_cus: a collective's CUs)
   int splits = (pp ? cus : 2 * cus) / tiles;
   const int max_splits = p.stages / 16 > 0 ? p.stages / 16 : 1;
   if (splits > max_splits) splits = max_splits;

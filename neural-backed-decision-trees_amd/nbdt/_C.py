@@ -61,6 +61,8 @@ SIGNATURES = {
     "nbdt_device_count": (c_int, []),
     "nbdt_set_deterministic": (c_int, [c_int32]),
     "nbdt_get_deterministic": (c_int, []),
+    "nbdt_set_reserved_cus": (c_int, [c_int32]),
+    "nbdt_get_reserved_cus": (c_int, []),
     "nbdt_tree_create": (c_int, [c_int, c_int, c_int, c_int, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P,
                                  POINTER(c_void_p)]),
     "nbdt_tree_destroy": (c_int, [c_void_p]),
@@ -91,6 +93,15 @@ SIGNATURES = {
     "nbdt_bn_bwd_cus": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
                                 c_int32, _P]),
     "nbdt_conv_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
+    "nbdt_ref_conv": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "nbdt_ref_wgrad": (c_int, [POINTER(WgradDesc), _P, _P, _P, _P]),
+    "nbdt_ref_bn_stats": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "nbdt_ref_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32,
+                                c_int32, _P, _P, _P, _P, _P, _P]),
+    "nbdt_ref_bn_relu_pool": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_stem_conv": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_stem_wgrad": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_weight_prep_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),
     "nbdt_weight_tile_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),

@@ -15,6 +15,41 @@ import os
 import torch
 import torch.distributed as dist
 
+# RCCL's footprint on the chip, chosen HERE rather than left to its tuner: an all-reduce kernel is one thread block per
+# channel, and every such block holds a CU that a one-block-per-CU MFMA kernel of the backward pass then cannot use.
+# 8 channels (one per XCD) move the 146 MB of WRN-28-10 gradients in ~1.7 ms at the ~20 GB/s a channel sustains over
+# xGMI -- inside the ~11 ms of backward they overlap with -- and cost the MFMA kernels 8 of 256 CUs while buckets are
+# in flight (engine.backward -> ops.set_reserved_cus).  NBDT_RCCL_CHANNELS overrides; an NCCL_MAX_NCHANNELS already
+# in the environment wins.
+DEFAULT_RCCL_CHANNELS = 8
+ASSUMED_GBPS_PER_CHANNEL = 20.0      # stated assumption until a multi-GPU node measures it (bench.py's `comm` object)
+RCCL = {"max_nchannels": None, "set_by": None}
+
+
+def rccl_channels():
+    """Channel bound in effect for RCCL (None: not a RCCL process group / left to RCCL)."""
+    return RCCL["max_nchannels"]
+
+
+def _bound_rccl_footprint():
+    if "NCCL_MAX_NCHANNELS" in os.environ:
+        RCCL.update(max_nchannels=int(os.environ["NCCL_MAX_NCHANNELS"]), set_by="NCCL_MAX_NCHANNELS (environment)")
+        return
+    n = int(os.environ.get("NBDT_RCCL_CHANNELS", DEFAULT_RCCL_CHANNELS))
+    os.environ["NCCL_MAX_NCHANNELS"] = str(n)           # read by RCCL when the communicator is created
+    RCCL.update(max_nchannels=n, set_by="NBDT_RCCL_CHANNELS" if "NBDT_RCCL_CHANNELS" in os.environ
+                else "nbdt.dist default")
+
+
+def allreduce_model_ms(nbytes, world, channels=None, gbps_per_channel=ASSUMED_GBPS_PER_CHANNEL):
+    """Time of a ring all-reduce of `nbytes` per rank under the stated per-channel rate: every rank sends and receives
+    2 (world - 1) / world of the buffer.  An ASSUMPTION-based model (no peer to measure against on a 1-GPU box); with
+    real peers bench.py reports the measured exposure beside it."""
+    if world <= 1:
+        return 0.0
+    channels = channels or rccl_channels() or DEFAULT_RCCL_CHANNELS
+    return 1e3 * (2.0 * (world - 1) / world * nbytes) / (channels * gbps_per_channel * 1e9)
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
@@ -28,6 +63,7 @@ def init_from_env(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
         if backend == "nccl":
+            _bound_rccl_footprint()
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
         else:
@@ -55,6 +91,17 @@ class GradComm:
         self.force = bool(force) and dist.is_initialized()
         self._stream = None
         self._work = []
+        # CUs the collective's kernels occupy while a bucket is in flight (one block per channel); 0 for gloo / 1 rank
+        rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" and (self.world_size > 1 or self.force)
+        self.reserved_cus = (rccl_channels() or DEFAULT_RCCL_CHANNELS) if rccl else 0
+
+    def describe(self, nbytes):
+        """What bench.py puts into its `comm` object about the exchange of `nbytes` per rank."""
+        return {"rccl_max_nchannels": rccl_channels(), "rccl_channels_set_by": RCCL["set_by"],
+                "reserved_cus_while_buckets_in_flight": self.reserved_cus,
+                "allreduce_model_ms": round(allreduce_model_ms(nbytes, self.world_size), 3),
+                "allreduce_model": f"ring, 2(N-1)/N x {nbytes} B per rank over {rccl_channels() or DEFAULT_RCCL_CHANNELS} "
+                                   f"channels x {ASSUMED_GBPS_PER_CHANNEL} GB/s (assumed per-channel xGMI rate)"}
 
     def reduce_range(self, flat, lo, hi):
         """Launch the all-reduce of flat[lo:hi]; everything already enqueued on the current stream

@@ -131,9 +131,19 @@ class Conv:
     def numel(self):
         return self.cout * self.taps * self.cin
 
+    def _w_for(self, x):
+        """Forward weights in the storage type of the activations: the bf16 mirror, or (verification-only fp32
+        reference mode) the fp32 master itself."""
+        return self.store.p(self.name) if x.dtype == torch.float32 else self.store.pb(self.name)
+
+    def _wd_for(self, g):
+        """Data-gradient weights [cin][taps][cout], tap order reversed: the bf16 copy weight_prep built, or an fp32
+        one (reference mode; plumbing on parameters, rebuilt by refresh_derived_weights)."""
+        return self.wd32 if g.dtype == torch.float32 else self.wd
+
     def forward(self, x, out, residual=None, bn_scratch=None):
         B, Hp, Wp, _ = x.shape
-        ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self.store.pb(self.name), out, residual, bn_scratch)
+        ops.conv_igemm(self.plan(B, Hp - 2, Wp - 2)[0], x, self._w_for(x), out, residual, bn_scratch)
 
     def forward_affine(self, x, out, bn, act=1, residual=None):
         """Inference: conv + eval-mode BatchNorm `bn` (folded to scale/shift) + activation [+ residual] in one
@@ -154,10 +164,10 @@ class Conv:
             ops.conv_igemm_bnbwd(descs[0], gout, self.wd, gin, bn_x, bn.mean, bn.rstd, bn.gamma, bn.beta, partials)
             return
         if len(descs) > 1 and self.merge_parity_classes:      # strided 3x3: four parity classes, one grid
-            ops.conv_igemm_multi(descs, gout, self.wd, gin)
+            ops.conv_igemm_multi(descs, gout, self._wd_for(gout), gin)
             return
         for d in descs:
-            ops.conv_igemm(d, gout, self.wd, gin)
+            ops.conv_igemm(d, gout, self._wd_for(gout), gin)
 
     def backward_weight(self, x, gout, cu_budget=0):
         """cu_budget: CUs this launch is sized for when it runs on the second stream (0 = all of them): the caller
@@ -259,6 +269,7 @@ class _Engine:
         self._bufs = {}
         self.convs, self.bns = [], []
         self.training = True
+        self.act_dtype = torch.bfloat16   # storage of activations / activation gradients (fp32: set_reference_fp32)
         self.debug_keep = False   # tests: give every unit its own gradient buffers (no reuse)
         self.debug_share_serial = False   # tests: the CU-sharing schedule's exact launches (CU counts, budgets) on ONE stream
         self.debug_join_each_unit = False # A/B: join the side stream at the top of every unit (the schedule before round 3)
@@ -304,7 +315,7 @@ class _Engine:
     def buf(self, key, B, H, W, C):
         k = (key, B, H, W, C)
         if k not in self._bufs:
-            self._bufs[k] = ops.padded(B, H, W, C, self.device)
+            self._bufs[k] = ops.padded(B, H, W, C, self.device, self.act_dtype)
         return self._bufs[k]
 
     def conv(self, name, cin, cout, k, stride, init="kaiming_a0"):
@@ -313,6 +324,25 @@ class _Engine:
             c.side_stream = self._side
         self.convs.append(c)
         return c
+
+    def set_reference_fp32(self, on=True):
+        """VERIFICATION ONLY.  Switch the storage of every activation / activation-gradient buffer to fp32: nbdt.ops then
+        routes each launch on such a buffer to the plain fp32 kernel of the same meaning (csrc/ref_fp32.hip) while this
+        engine keeps doing exactly what it does in production -- the same forward() / backward() code, launch order,
+        two streams, events, rotating buffers, fused-statistics and CU-sharing protocol.  With fp32 storage a whole
+        training step must agree with the fp32 oracle to ~1e-5; with bf16 storage the same path agrees to a gradient
+        cosine of ~0.9 (mask flips from 1-ulp roundings).  The difference between the two is storage precision and
+        nothing else -- that is the statement tests/test_reference_fp32_gpu.py makes.  Slow (one thread per output);
+        small models and batches only.  Inference fusion (conv + folded BatchNorm) has no fp32 twin: eval-mode
+        forwards run unfused."""
+        self.join_side_stream()
+        self.act_dtype = torch.float32 if on else torch.bfloat16
+        self.fuse_eval = not on
+        self._bufs = {}
+        for c in self.convs:
+            c._plans = {}
+        self._share_calibrated = True        # (a timing decision between two schedules of the SLOW kernels means nothing)
+        self.refresh_derived_weights()
 
     def set_overlap(self, on):
         """Turn the second (weight-gradient) stream on/off at run time; off = every launch on the caller's stream,
@@ -492,6 +522,15 @@ class _Engine:
             self._cu_share = None
         return self.cu_share_report
 
+    def _reserve_for(self, comm):
+        """While gradient buckets are in flight the collective's kernels hold `comm.reserved_cus` CUs (one RCCL block
+        per channel): the one-block-per-CU MFMA launches that follow are sized for the rest (ops.set_reserved_cus), so
+        none of their persistent blocks waits for a CU an all-reduce block holds.  comm=None: back to the whole chip."""
+        n = int(getattr(comm, "reserved_cus", 0) or 0) if comm is not None else 0
+        if n != getattr(self, "_reserved_now", 0):
+            ops.set_reserved_cus(n)
+            self._reserved_now = n
+
     def join_side_stream(self):
         """Order every weight-gradient launch issued on the side stream before what follows on the main one."""
         if self._side is not None:
@@ -551,6 +590,9 @@ class _Engine:
     def refresh_derived_weights(self):
         for b in self.bns:             # gamma / beta may have changed: drop the folded eval transforms
             b._affine = None
+        if self.act_dtype == torch.float32:      # reference mode: fp32 data-gradient weights (plumbing on parameters)
+            for c in self.convs:
+                c.wd32 = self.store.p(c.name).flip(1).permute(2, 1, 0).contiguous()
         if self._wt_n:     # forward tiles are needed by the very next forward: caller's stream
             ops.weight_tile_batched(self.store.bf16, self._wt_ftable, self._wt_n, self._wt_ftotal, self._wt_fwd)
         if self._side is None or not getattr(self, "_overlap", True):
@@ -877,11 +919,13 @@ class WRNEngine(_Engine):
             if comm is not None and u["key"] in ("s3u1", "s2u1"):
                 self.join_side_stream()
                 comm.reduce_range(st.grad, *buckets[0 if u["key"] == "s3u1" else 1])
+                self._reserve_for(comm)
         ops.stem_wgrad(self._img, g, st.g("features.init_block.weight"), self.stem_c)
         self.join_side_stream()      # every gradient is complete on the caller's stream when backward returns
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])
             comm.finish(st.grad)
+            self._reserve_for(None)
 
     # ------------------------------------------------------------------ reference-named views
     def extra_param_views(self, buf):
@@ -1030,10 +1074,8 @@ class ResNetEngine(_Engine):
         g = self.buf(f"g_out{self.feat_c}", B, h, w, self.feat_c)
         # plain avg-pool backward: identity BN with zero batch sums (the x>0 mask it applies is the
         # same mask the following ReLU backward applies anyway)
-        from nbdt._C import check, lib, ptr
-        check(lib().nbdt_pool_bn_bwd_apply(ptr(gpool), ptr(self._x_last), ptr(self._id_mean), ptr(self._id_rstd),
-                                           ptr(self._id_gamma), ptr(self._id_beta), ptr(self._id_dsum), B, h, w,
-                                           self.feat_c, ptr(g), ops.stream_ptr(self.device)))
+        ops.pool_bn_bwd_apply(gpool, self._x_last, self._id_mean, self._id_rstd, self._id_gamma, self._id_beta,
+                              self._id_dsum, g)
         toggle, n_blk, side_mark = 0, 0, None
         two_streams = self._side is not None and self._overlap
         if two_streams:
@@ -1088,6 +1130,7 @@ class ResNetEngine(_Engine):
             if comm is not None and k in ("l3b0", "l2b0"):
                 self.join_side_stream()
                 comm.reduce_range(st.grad, *buckets[0 if k == "l3b0" else 1])
+                self._reserve_for(comm)
         gt0 = self.buf("gt0", B, h, w, 64)
         self.bn0.backward(g, None, self.buf("t0", B, h, w, 64), gt0, relu=True)
         ops.stem_wgrad(self._img, gt0, st.g("conv1.weight"), 64)
@@ -1095,6 +1138,7 @@ class ResNetEngine(_Engine):
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])
             comm.finish(st.grad)
+            self._reserve_for(None)
 
 
 def train_step(engine, criterion, img, targets, lr, momentum=0.9, weight_decay=5e-4, comm=None, fused_head=True,

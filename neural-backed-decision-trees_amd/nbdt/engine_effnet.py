@@ -362,6 +362,7 @@ class EfficientNetEngine(_Engine):
             if comm is not None and k in ("s5u1", "s3u1"):
                 self.join_side_stream()
                 comm.reduce_range(st.grad, *buckets[0 if k == "s5u1" else 1])
+                self._reserve_for(comm)
         bn = self.bn0
         t0 = self.buf("t0", B, h, w, _pad32(self.stem_c))
         ops.bn_act_bwd(g, t0, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
@@ -371,3 +372,4 @@ class EfficientNetEngine(_Engine):
         if comm is not None:
             comm.reduce_range(st.grad, *buckets[2])
             comm.finish(st.grad)
+            self._reserve_for(None)

@@ -32,9 +32,30 @@ def is_deterministic():
     return bool(lib().nbdt_get_deterministic())
 
 
-def padded(B, H, W, C, device):
-    """Zero-initialised padded NHWC bf16 activation buffer."""
-    return torch.zeros((B, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+def set_reserved_cus(n):
+    """CUs the one-block-per-CU MFMA kernels leave free for a collective's kernels (nbdt_set_reserved_cus)."""
+    check(lib().nbdt_set_reserved_cus(int(n)))
+
+
+def reserved_cus():
+    return int(lib().nbdt_get_reserved_cus())
+
+
+def padded(B, H, W, C, device, dtype=torch.bfloat16):
+    """Zero-initialised padded NHWC activation buffer: bf16 (the product path), or fp32 for the engines'
+    verification-only reference mode (see _ref below)."""
+    return torch.zeros((B, H + 2, W + 2, C), dtype=dtype, device=device)
+
+
+def _no_ref(t, what):
+    if t.dtype == torch.float32:
+        raise RuntimeError(f"fp32 reference mode has no twin of {what}")
+
+
+def _ref(t):
+    """fp32 padded tensors select the verification-only kernels of csrc/ref_fp32.hip (engine.set_reference_fp32): same
+    operator, same descriptors, fp32 storage.  The product path never creates an fp32 activation buffer."""
+    return t.dtype == torch.float32
 
 
 def interior(t):
@@ -205,6 +226,14 @@ def set_timer(t):
 
 def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
     """bn_scratch: also accumulate the output's per-channel sum / sum-of-squares for the next BatchNorm."""
+    if _ref(inp):
+        check(lib().nbdt_ref_conv(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
+                                  stream_ptr(inp.device)))
+        if bn_scratch is not None:      # the epilogue's statistics: row 0 of the partial table, folded by bn_finalize
+            B, H, W, C = _dims(out)
+            check(lib().nbdt_ref_bn_stats(ptr(out), B, H, W, C, BN_EPS, BN_MOMENTUM, None, None, None, None,
+                                          ptr(bn_scratch), stream_ptr(inp.device)))
+        return
     ev = None
     if _timer is not None and _timer.wants("conv_igemm"):
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
@@ -223,6 +252,10 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
 
 def conv_igemm_multi(descs, inp, w_bf16, out):
     """The launches of `descs` (<= 4, same operands: the parity classes of a strided 3x3 data gradient) in one grid."""
+    if _ref(inp):
+        for d in descs:
+            check(lib().nbdt_ref_conv(ctypes.byref(d), ptr(inp), ptr(w_bf16), ptr(out), None, stream_ptr(inp.device)))
+        return
     arr = (ConvDesc * len(descs))(*descs)
     ev = None
     if _timer is not None and _timer.wants("conv_igemm"):
@@ -237,6 +270,7 @@ def conv_igemm_multi(descs, inp, w_bf16, out):
 
 def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, partials):
     """dgrad launch that also produces the BatchNorm-backward sums of (out, bn_x) as per-tile partials."""
+    _no_ref(inp, "conv_igemm_bnbwd (fused BatchNorm-backward sums): use the split or the unfused schedule")
     ev = None
     if _timer is not None and _timer.wants("conv_igemm"):
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
@@ -251,6 +285,7 @@ def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, part
 
 def conv_igemm_affine(desc, inp, w_bf16, out, scale, shift, act=1, residual=None):
     """Inference launch: out = act(conv * scale[c] + shift[c] [+ residual]) (act: 0 none, 1 ReLU, 2 swish)."""
+    _no_ref(inp, "conv_igemm_affine (folded eval-mode BatchNorm): engine.fuse_eval is off in reference mode")
     check(lib().nbdt_conv_igemm_affine(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(residual),
                                        ptr(scale), ptr(shift), act, stream_ptr(inp.device)))
 
@@ -259,6 +294,7 @@ def bn_bwd_fused(gy, x, mean, rstd, gamma, beta, partials, dsum, dgamma, dbeta, 
     """BatchNorm(+ReLU) backward when the producing dgrad already left the reduction partials.
     cus > 0: the apply pass runs on that many CUs only (nbdt_bn_bwd_apply_cus) -- the caller has a weight gradient
     with cu_budget = 256 - cus in flight on another stream."""
+    _no_ref(x, "bn_bwd_fused: use the split or the unfused schedule")
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
     check(lib().nbdt_bn_bwd_fold(B, H, W, C, ptr(partials), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
@@ -277,6 +313,10 @@ def bn_bwd_cus(gy, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx,
     the elementwise pass; `slots` is left dirty and `slots_other` zeroed, so the caller swaps them for the next call."""
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_bwd(ptr(gy), None, None, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), 1,
+                                    ptr(gx_add), B, H, W, C, 1, ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx), None, st))
+        return
     if isinstance(scratch, (tuple, list)):
         slots, other = scratch
         check(lib().nbdt_bn_bwd_cus(ptr(gy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(gx_add), B, H, W,
@@ -292,6 +332,9 @@ def bn_bwd_cus(gy, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx,
 def conv_wgrad(desc, x, gy, dw, cu_budget=0):
     """cu_budget: size the launch for that many CUs (0 = all) -- see nbdt_wgrad_desc.cu_budget."""
     desc.cu_budget = int(cu_budget)
+    if _ref(x):
+        check(lib().nbdt_ref_wgrad(ctypes.byref(desc), ptr(x), ptr(gy), ptr(dw), stream_ptr(x.device)))
+        return
     ev = None
     if _timer is not None and _timer.wants("conv_wgrad"):
         flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
@@ -328,17 +371,19 @@ def plan_cu_share(desc, elements, tensors, gbps_per_cu, target_us, min_cus, max_
     weight-gradient block to finish there and the pass takes as long as both (measured: 19.1 -> 27 ms per step
     whenever the dispatch order fell that way).  A budget whose blocks would leave the pass less than one CU per XCD
     is lowered by 8 until they do, so the pass never gets 0 CUs.  Host arithmetic only."""
-    per_xcd = MI355X_CUS // MI355X_XCDS
+    held = (reserved_cus() + MI355X_XCDS - 1) // MI355X_XCDS      # per XCD: CUs a collective's kernels hold right now
+    per_xcd = MI355X_CUS // MI355X_XCDS - held
+    cus = per_xcd * MI355X_XCDS                                    # what the pair has to share
     n = int(round(elements * 2 * tensors / (gbps_per_cu * 1e9 * target_us * 1e-6)))
     n = max(max(8, int(min_cus)), min(int(max_cus), n))
-    n = min(n, MI355X_CUS - MI355X_XCDS)
+    n = min(n, cus - MI355X_XCDS)
     while True:
-        blocks = conv_wgrad_blocks(desc, MI355X_CUS - n)
-        if not 0 < blocks <= MI355X_CUS - n:      # not the one-block-per-CU kernel (small problems): the model's n
-            return MI355X_CUS - n, n
+        blocks = conv_wgrad_blocks(desc, cus - n)
+        if not 0 < blocks <= cus - n:             # not the one-block-per-CU kernel (small problems): the model's n
+            return cus - n, n
         free = MI355X_XCDS * (per_xcd - (blocks + MI355X_XCDS - 1) // MI355X_XCDS)
-        if free >= MI355X_XCDS or n + MI355X_XCDS > MI355X_CUS - MI355X_XCDS:
-            return MI355X_CUS - n, max(free, MI355X_XCDS)
+        if free >= MI355X_XCDS or n + MI355X_XCDS > cus - MI355X_XCDS:
+            return cus - n, max(free, MI355X_XCDS)
         n += MI355X_XCDS
 
 
@@ -389,6 +434,10 @@ def bn_stats(x, scratch, save_mean, save_rstd, running_mean=None, running_var=No
              eps=BN_EPS, momentum=BN_MOMENTUM, slots_filled=False):
     """slots_filled: the producing kernel already accumulated the sums into `scratch` (fold only)."""
     B, H, W, C = _dims(x)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_stats(ptr(x), B, H, W, C, eps, momentum, ptr(running_mean), ptr(running_var),
+                                      ptr(save_mean), ptr(save_rstd), None, stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_stats(None if slots_filled else ptr(x), B, H, W, C, eps, momentum, ptr(running_mean), ptr(running_var),
                               ptr(scratch), ptr(save_mean), ptr(save_rstd), stream_ptr(x.device)))
 
@@ -403,6 +452,10 @@ def bn_finalize(x, scratch, save_mean, save_rstd, running_mean=None, running_var
 
 def bn_apply(x, mean, rstd, gamma, beta, y, relu=True, residual=None):
     B, H, W, C = _dims(x)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual),
+                                      1 if relu else 0, B, H, W, C, ptr(y), stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual),
                               1 if relu else 0, B, H, W, C, ptr(y), stream_ptr(x.device)))
 
@@ -413,6 +466,11 @@ def bn_bwd(gy, y, x, mean, rstd, gamma, scratch, dsum, dgamma, dbeta, gx, relu=T
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
     r = 1 if relu else 0
+    if _ref(x):
+        check(lib().nbdt_ref_bn_bwd(ptr(gy), None, ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), r,
+                                    ptr(gx_add), B, H, W, C, 1, ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx), ptr(g_resid),
+                                    st))
+        return
     check(lib().nbdt_bn_bwd_reduce(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), r,
                                    B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
     check(lib().nbdt_bn_bwd_apply(ptr(gy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
@@ -421,6 +479,10 @@ def bn_bwd(gy, y, x, mean, rstd, gamma, scratch, dsum, dgamma, dbeta, gx, relu=T
 
 def bn_relu_pool(x, mean, rstd, gamma, beta, pooled):
     B, H, W, C = _dims(x)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_relu_pool(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, H, W, C, ptr(pooled),
+                                          stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_relu_pool(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, H, W, C,
                                   ptr(pooled), stream_ptr(x.device)))
 
@@ -428,20 +490,45 @@ def bn_relu_pool(x, mean, rstd, gamma, beta, pooled):
 def pool_bn_bwd(gpooled, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx):
     B, H, W, C = _dims(x)
     st = stream_ptr(x.device)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_bwd(None, ptr(gpooled), None, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), 1,
+                                    None, B, H, W, C, 1, ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx), None, st))
+        return
     check(lib().nbdt_pool_bn_bwd_reduce(ptr(gpooled), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                                         B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), st))
     check(lib().nbdt_pool_bn_bwd_apply(ptr(gpooled), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                                        ptr(dsum), B, H, W, C, ptr(gx), st))
 
 
+def pool_bn_bwd_apply(gpooled, x, mean, rstd, gamma, beta, dsum, gx):
+    """Elementwise pass of the pooled head's backward alone, with the caller's sums (ResNetEngine: a plain average pool
+    is an identity BatchNorm with zero batch sums)."""
+    B, H, W, C = _dims(x)
+    st = stream_ptr(x.device)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_bwd(None, ptr(gpooled), None, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), 1,
+                                    None, B, H, W, C, 0, ptr(dsum), None, None, ptr(gx), None, st))
+        return
+    check(lib().nbdt_pool_bn_bwd_apply(ptr(gpooled), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dsum),
+                                       B, H, W, C, ptr(gx), st))
+
+
 def stem_conv(img, w, out, cout_real, stride=1):
     B, _, H, W = img.shape
+    if _ref(out):
+        check(lib().nbdt_ref_stem_conv(ptr(img), ptr(w), B, H, W, cout_real, out.shape[3], stride, ptr(out),
+                                       stream_ptr(img.device)))
+        return
     check(lib().nbdt_stem_conv(ptr(img), ptr(w), B, H, W, cout_real, out.shape[3], stride, ptr(out),
                                stream_ptr(img.device)))
 
 
 def stem_wgrad(img, gy, dw, cout_real, stride=1):
     B, _, H, W = img.shape
+    if _ref(gy):
+        check(lib().nbdt_ref_stem_wgrad(ptr(img), ptr(gy), B, H, W, cout_real, gy.shape[3], stride, ptr(dw),
+                                        stream_ptr(img.device)))
+        return
     check(lib().nbdt_stem_wgrad(ptr(img), ptr(gy), B, H, W, cout_real, gy.shape[3], stride, ptr(dw),
                                 stream_ptr(img.device)))
 

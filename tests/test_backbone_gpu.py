@@ -321,6 +321,51 @@ def test_batchnorm_backward_with_the_fold_inside_the_elementwise_pass(B, H, W, C
     assert ((gx.float() - gx_r.float()).abs() <= tol).all()
 
 
+def test_mfma_launches_leave_reserved_cus_free():
+    """nbdt_set_reserved_cus(n): the persistent forward / data-gradient kernel runs 8 x (32 - ceil(n/8)) blocks and the
+    weight gradient is sized for at most 256 - n CUs (a collective's kernels hold the rest).  Same tiles, other block ->
+    tile assignment: the conv output is bit-identical, its per-tile statistics and the weight gradient equal up to
+    the order of their fp32 sums; the CU-sharing plan gives the BatchNorm pass none of the reserved CUs."""
+    B, H, W, C = 128, 32, 32, 160
+    g = torch.Generator().manual_seed(5)
+    x = ops.padded(B, H, W, C, DEV); ops.interior(x).copy_(torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV))
+    gy = ops.padded(B, H, W, C, DEV); ops.interior(gy).copy_(torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV))
+    w = (torch.randn(C, 9, C, generator=g) * 0.05).to(DEV)
+    wb = w.to(torch.bfloat16)
+    d = ops.conv_fwd_desc(B, H, H, C, C, 3, 1)
+    wt = ops.weight_tiles(wb)              # (kept alive: the descriptor only holds its address)
+    d.w_tiled = wt.data_ptr()
+    d.wide_tile = 2
+    dw_desc = ops.conv_wgrad_desc(B, H, H, C, C, 3, 1)
+    rows = (B * H * W + 255) // 256
+    outs = {}
+    try:
+        for n in (0, 8, 20, 64):
+            ops.set_reserved_cus(n)
+            assert ops.reserved_cus() == n
+            out, part = ops.padded(B, H, W, C, DEV), torch.zeros(rows * 2 * C, device=DEV)
+            ops.conv_igemm(d, x, wb, out, bn_scratch=part)
+            assert ops.last_igemm_kernel() == "conv3x3_pp_kernel"
+            dw = torch.zeros(C, 9, C, device=DEV)
+            ops.conv_wgrad(dw_desc, x, gy, dw)
+            blocks = ops.conv_wgrad_blocks(dw_desc, 0)
+            assert 0 < blocks <= 256 - n, (n, blocks)
+            budget, cus = ops.plan_cu_share(dw_desc, B * H * W * C, 5, 47.0, 190.0, 16, 128)
+            held = (n + 7) // 8
+            assert ops.conv_wgrad_blocks(dw_desc, budget) + cus <= 8 * (32 - held), (n, budget, cus)
+            outs[n] = (out, part, dw)
+    finally:
+        ops.set_reserved_cus(0)
+    assert outs[0][0].float().abs().max() > 0
+    for n in (8, 20, 64):
+        assert torch.equal(outs[n][0], outs[0][0]), n
+        # (a tile's statistics are summed with LDS atomics: equal up to their order, run to run)
+        assert (outs[n][1] - outs[0][1]).abs().max().item() <= 1e-4 * outs[0][1].abs().max().item(), n
+        assert (outs[n][2] - outs[0][2]).abs().max().item() <= 1e-3 * outs[0][2].abs().max().item(), n
+    with pytest.raises(_C.NBDTHipError):
+        ops.set_reserved_cus(200)
+
+
 @pytest.mark.parametrize("B,H,W,C,expect", [(128, 32, 32, 160, {0: 250, 208: 205, 192: 190}),
                                             (256, 16, 16, 320, {0: 240, 232: 220, 176: 160}),
                                             (512, 8, 8, 640, {0: 240, 232: 160})])

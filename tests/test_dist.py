@@ -128,3 +128,33 @@ def test_data_parallel_step_equals_per_shard_oracle_average(tmp_path, pkg_dir):
     got = [np.load(tmp_path / f"params{r}.npy") for r in range(world)]
     assert np.array_equal(got[0], got[1])                      # replicas stay bit-identical
     np.testing.assert_allclose(got[0], expect.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# RCCL's footprint is bounded by this package, not left to RCCL's tuner: the channel count
+# is set before the communicator is created and reported; the exposed-all-reduce model is plain arithmetic.
+
+def test_rccl_channel_bound_and_allreduce_model(monkeypatch):
+    nbdt_path.add()
+    from nbdt import dist as ndist
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("NBDT_RCCL_CHANNELS", raising=False)
+    ndist._bound_rccl_footprint()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "8" and ndist.rccl_channels() == 8
+    assert ndist.RCCL["set_by"] == "nbdt.dist default"
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.setenv("NBDT_RCCL_CHANNELS", "16")
+    ndist._bound_rccl_footprint()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "16" and ndist.rccl_channels() == 16
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "4")              # an explicit RCCL setting wins
+    ndist._bound_rccl_footprint()
+    assert ndist.rccl_channels() == 4 and "environment" in ndist.RCCL["set_by"]
+    # ring all-reduce: 2 (N-1)/N of the buffer per rank at channels x 20 GB/s
+    nbytes = 146_000_000
+    assert ndist.allreduce_model_ms(nbytes, 1) == 0.0
+    assert abs(ndist.allreduce_model_ms(nbytes, 8, channels=8) - 1e3 * 1.75 * nbytes / 160e9) < 1e-9
+    assert abs(ndist.allreduce_model_ms(nbytes, 2, channels=8) - 1e3 * nbytes / 160e9) < 1e-9
+    ndist.RCCL.update(max_nchannels=None, set_by=None)
+    # a gloo / single-process GradComm holds no CUs
+    comm = ndist.GradComm()
+    assert comm.reserved_cus == 0 and comm.describe(nbytes)["allreduce_model_ms"] == 0.0

@@ -39,6 +39,18 @@ def test_rccl_bucketed_allreduce_in_a_one_rank_group():
             assert abs(a - b) < 2e-2 * abs(a), (losses["plain"], losses["rccl"])
         rel = (losses["plain_p"] - losses["rccl_p"]).norm() / losses["plain_p"].norm()
         assert rel.item() < 3e-2
+        # while buckets are in flight the MFMA launches leave RCCL's CUs free; afterwards the whole chip again
+        from nbdt import ops
+        comm = ndist.GradComm(force=True)
+        assert comm.reserved_cus == ndist.DEFAULT_RCCL_CHANNELS and ops.reserved_cus() == 0
+        seen = []
+        real = ops.set_reserved_cus
+        ops.set_reserved_cus = lambda n: (seen.append(n), real(n))[1]
+        try:
+            train_step(eng, crit, x, y, lr=0.05, comm=comm)
+        finally:
+            ops.set_reserved_cus = real
+        assert seen == [comm.reserved_cus, 0] and ops.reserved_cus() == 0
         # raw collective on a slice of a flat buffer, issued from the side stream
         flat = torch.arange(1024, dtype=torch.float32, device="cuda")
         comm = ndist.GradComm(force=True)

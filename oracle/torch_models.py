@@ -200,17 +200,25 @@ class _Swish(nn.Module):
 
 
 class _ConvBlock(nn.Module):
-    """pytorchcv ConvBlock: conv (bias-free) + BatchNorm + optional Swish."""
+    """pytorchcv ConvBlock: conv (bias-free) + BatchNorm + optional Swish.
+    Under emulate_bf16 the raw conv output is rounded (every engine stores it), the 1x1 convs read bf16 weights
+    (`w_bf16`; the stem and the depthwise kernels read the fp32 masters), and the block's output is rounded only where
+    the EfficientNet engine stores it (`round_out`: not after a depthwise conv -- swish(bn(.)) exists only inside its
+    kernels -- nor after the project conv, whose output is stored after the skip add, nor after the final block)."""
 
-    def __init__(self, cin, cout, k, stride=1, groups=1, act=True):
+    def __init__(self, cin, cout, k, stride=1, groups=1, act=True, round_out=True, w_bf16=True):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, groups=groups, bias=False)
         self.bn = nn.BatchNorm2d(cout, eps=1e-5)
         self.act = act
+        self.round_out = round_out
+        self.w_bf16 = w_bf16 and groups == 1
 
     def forward(self, x):
-        x = self.bn(self.conv(x))
-        return x * torch.sigmoid(x) if self.act else x
+        x = _q(_conv(self.conv, x) if self.w_bf16 else self.conv(x))
+        x = self.bn(x)
+        x = x * torch.sigmoid(x) if self.act else x
+        return _q(x) if self.round_out else x
 
 
 class _SEBlock(nn.Module):
@@ -224,20 +232,20 @@ class _SEBlock(nn.Module):
         w = self.conv1(w)
         w = w * torch.sigmoid(w)
         w = torch.sigmoid(self.conv2(w))
-        return x * w
+        return _q(x * w)                 # (the gated activation is what the engine stores: d_se)
 
 
 class _EffiDwsConvUnit(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
         self.residual = cin == cout and stride == 1
-        self.dw_conv = _ConvBlock(cin, cin, 3, stride, groups=cin)
+        self.dw_conv = _ConvBlock(cin, cin, 3, stride, groups=cin, round_out=False)
         self.se = _SEBlock(cin, cin // 4)
-        self.pw_conv = _ConvBlock(cin, cout, 1, act=False)
+        self.pw_conv = _ConvBlock(cin, cout, 1, act=False, round_out=False)
 
     def forward(self, x):
         y = self.pw_conv(self.se(self.dw_conv(x)))
-        return y + x if self.residual else y
+        return _q(y + x if self.residual else y)
 
 
 class _EffiInvResUnit(nn.Module):
@@ -246,19 +254,19 @@ class _EffiInvResUnit(nn.Module):
         self.residual = cin == cout and stride == 1
         mid = cin * exp_factor
         self.conv1 = _ConvBlock(cin, mid, 1)
-        self.conv2 = _ConvBlock(mid, mid, k, stride, groups=mid)
+        self.conv2 = _ConvBlock(mid, mid, k, stride, groups=mid, round_out=False)
         self.se = _SEBlock(mid, mid // (exp_factor * se_factor))
-        self.conv3 = _ConvBlock(mid, cout, 1, act=False)
+        self.conv3 = _ConvBlock(mid, cout, 1, act=False, round_out=False)
 
     def forward(self, x):
         y = self.conv3(self.se(self.conv2(self.conv1(x))))
-        return y + x if self.residual else y
+        return _q(y + x if self.residual else y)
 
 
 class _InitBlock(nn.Module):
     def __init__(self, cout):
         super().__init__()
-        self.conv = _ConvBlock(3, cout, 3, stride=2)
+        self.conv = _ConvBlock(3, cout, 3, stride=2, w_bf16=False)
 
     def forward(self, x):
         return self.conv(x)
@@ -288,7 +296,7 @@ class EfficientNetB0(nn.Module):
                 stage.add_module(f"unit{j + 1}", unit)
                 cin = cout
             feats.add_module(f"stage{i + 1}", stage)
-        feats.add_module("final_block", _ConvBlock(cin, 1280, 1))
+        feats.add_module("final_block", _ConvBlock(cin, 1280, 1, round_out=False))
         feats.add_module("final_pool", nn.AdaptiveAvgPool2d(1))
         self.features = feats
         self.output = nn.Sequential()

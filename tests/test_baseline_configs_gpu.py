@@ -170,31 +170,46 @@ def test_config4_resnet18_tinyimagenet200_hard_nbdt(pkg_dir):
 
 def test_config5_efficientnet_b0_imagenet1000(pkg_dir):
     """configs[4]: EfficientNet-B0 + SoftNBDT on the 1000-leaf Imagenet1000 induced-efficientnet_b7b hierarchy,
-    224x224 images, 8 images of a rank's shard (the fp32 autograd oracle of 224x224 MBConv stacks is the limit);
-    dropout off so that both paths are deterministic functions of the same weights."""
+    224x224 images, 32 images of a rank's shard; dropout off so that both paths are deterministic functions of the same
+    weights.  Two comparators: the fp32 CPU oracle, and the SAME oracle rounding to bf16 at the engine's storage points
+    (torch_models.emulate_bf16: raw conv outputs, stored activations, 1x1-conv weights, the matching gradients) --
+    against the latter the logits must agree to 5 % of their scale (~80 storage points between image and logits, each
+    renormalised by a BatchNorm; what is left is summation order snapping to 1-ulp bf16 differences)."""
     from nbdt.engine_effnet import EfficientNetEngine
     torch.manual_seed(0)
     ref = TM.EfficientNetB0(num_classes=1000, dropout_rate=0.0)
+    init = {k: v.clone() for k, v in ref.state_dict().items()}
     eng = EfficientNetEngine(num_classes=1000, dropout_rate=0.0, device=DEV)
-    eng.load_state_dict(ref.state_dict())
+    eng.load_state_dict(init)
     g = torch.Generator().manual_seed(51)
-    x = torch.randn(8, 3, 224, 224, generator=g)
-    y = torch.randint(0, 1000, (8,), generator=g)
+    x = torch.randn(32, 3, 224, 224, generator=g)
+    y = torch.randint(0, 1000, (32,), generator=g)
     m = _train_step_vs_oracle(ref, eng, "Imagenet1000", "induced-efficientnet_b7b", pkg_dir, x, y)
-    _report("config 5", m)
-    # ~80 bf16 storage points between image and logits, each renormalised by a BatchNorm
-    assert m["logit_err"] < 0.15 * m["scale"]
+    _report("config 5 vs fp32 oracle", m)
+    assert m["logit_err"] < 0.06 * m["scale"]       # measured 3.1 % (the 8-image version of round 3 allowed 15 %)
     assert abs(m["loss"] - m["loss_ref"]) < 2e-2 * abs(m["loss_ref"])
     assert m["hard_same_logits"] and m["soft_argmax_same_logits"]
     bad = []
     for name, c, ratio, gn in m["grads"]:
         if gn < 1e-6:
             continue        # mathematically zero gradients (a BatchNorm shift feeding conv -> BatchNorm)
-        # (8 images make the squeeze-excite gradients small and noisy: before deterministic mode covered the MBConv
-        # kernels these came out 0.92-0.95 / 0.95-1.12 at worst, by run)
-        if not (c > 0.88 and abs(ratio - 1) < 0.25):
+        if not (c > 0.93 and abs(ratio - 1) < 0.25):     # measured: worst cosine 0.98, norm ratios 0.87 .. 1.06
             bad.append((name, round(c, 4), round(ratio, 4)))
     assert not bad, bad
+    # second comparator: the bf16-emulating oracle, same weights, same batch (one more engine step on fresh statistics)
+    ref2 = TM.EfficientNetB0(num_classes=1000, dropout_rate=0.0)
+    ref2.load_state_dict(init)
+    eng.load_state_dict(init)
+    with TM.emulate_bf16():
+        m2 = _train_step_vs_oracle(ref2, eng, "Imagenet1000", "induced-efficientnet_b7b", pkg_dir, x, y)
+    _report("config 5 vs bf16-emulating oracle", m2)
+    assert m2["logit_err"] < 0.05 * m2["scale"], (m2["logit_err"], m2["scale"])
+    assert abs(m2["loss"] - m2["loss_ref"]) < 1e-2 * abs(m2["loss_ref"])
+    # (same exclusion as above, by NAME: under emulation the rounding noise gives the mathematically zero gradients a
+    # small random value)
+    zero = {r[0] for r in m["grads"] if r[3] < 1e-6}
+    live = [r for r in m2["grads"] if r[0] not in zero]
+    assert min(r[1] for r in live) > 0.88, min(live, key=lambda r: r[1])
     # SoftNBDT inference output of the same logits: probabilities, rows sum to 1, equal to the oracle's on those logits
     tree = Tree("Imagenet1000", hierarchy="induced-efficientnet_b7b")
     z = eng.forward(x.to(DEV), training=False).float()

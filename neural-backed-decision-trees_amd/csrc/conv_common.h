@@ -77,6 +77,10 @@ struct EpiLds {
   unsigned char* region;   // this wave's 32 rows x (2*BN + 16) bytes
   int* row_off;            // this wave's 64 entries
   float* blk_stats;        // [2][BN], shared by the block
+  // where EVERY wave's region is (the statistics fold reads all of them): waves [0, n_a) at base_a + w * REGION,
+  // the others at base_b + (w - n_a) * REGION
+  unsigned char *base_a, *base_b;
+  int n_a;
 };
 template <int NT, int NWV>
 __device__ __forceinline__ EpiLds epi_lds_packed(unsigned char* smem, int wave) {   // everything from smem + 0
@@ -85,6 +89,7 @@ __device__ __forceinline__ EpiLds epi_lds_packed(unsigned char* smem, int wave) 
   l.region = smem + wave * REGION;
   l.row_off = (int*)(smem + NWV * REGION) + wave * 64;
   l.blk_stats = (float*)(smem + NWV * REGION + NWV * 64 * 4);
+  l.base_a = smem; l.base_b = smem; l.n_a = NWV;
   return l;
 }
 struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
@@ -113,6 +118,19 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   constexpr int NCH = BN / 8;            // 8-channel chunks per row
   constexpr int RL = 64 / NCH;           // row lanes: lanes [0, RL*NCH) are active in the row walk
   constexpr int ROW_ITERS = (32 + RL - 1) / RL;
+  constexpr int REGION_BYTES = 32 * PITCH;
+  // The block's statistics: every walker lane ends up with 16 partial sums (8 channels x {sum, second sum}).  They used
+  // to go into blk_stats with LDS atomics (ds_add_f32, 16 per lane): 24 lanes of the block add to every address, and
+  // that tail took 25 k cycles per 512-pixel tile -- 40-80 us of a 32x32x160 launch (s_memtime stamps,
+  // profiles/r04_pp_epilogue_phases.txt).  Now each wave parks its lanes' partials in its own transposition region
+  // (free after its last row walk), one barrier, and 2*BN threads add the NWV * RL partials of their channel in a fixed
+  // order: no atomics, ~1 k cycles, and run-to-run identical bits without a deterministic-mode special case.
+  // (NT == 1: a wave's 64 x 64 B of partials do not fit its 2.5 KB region -- those small launches keep the atomics.)
+#ifdef NBDT_EPI_STATS_ATOMICS      // A/B build (scratch/variants): the LDS-atomic form everywhere
+  constexpr bool STATS_VIA_REGIONS = false;
+#else
+  constexpr bool STATS_VIA_REGIONS = RL * NCH * 64 <= REGION_BYTES;
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();          // every wave is done with the K ring
   asm volatile("" ::: "memory");
@@ -123,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   {
     const int m = m0 + wave * 64 + lane;
     row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
-    if (STATS == 1 || STATS == 2) {
+    if ((STATS == 1 || STATS == 2) && !STATS_VIA_REGIONS) {
       for (int i = tid; i < 2 * BN; i += NTHR) blk_stats[i] = 0.f;
       __syncthreads();   // block-uniform: zeroed before any wave's atomics
     }
@@ -258,38 +276,63 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
     NBDT_EPI_STAMP(3 + 2 * tm)
   }
   if (STATS == 1 || STATS == 2) {
-    if (p.deterministic) {
-      // fixed order: wave 0's row lanes 0, 1, ..., then wave 1's, ... -- one turn per barrier, plain read-modify-write
-      // (lanes of one turn hold distinct channel chunks).  NWV * RL barriers per tile: a debugging mode, not a fast one.
-      for (int w = 0; w < NWV; ++w)
-        for (int r = 0; r < RL; ++r) {
-          if (wave == w && walker && rl == r)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              blk_stats[ch * 8 + i] += s1[i];
-              blk_stats[BN + ch * 8 + i] += s2[i];
-            }
-          __syncthreads();
-        }
-    } else {
-      if (walker)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          atomicAdd(blk_stats + ch * 8 + i, s1[i]);
-          atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
-        }
-      __syncthreads();
-    }
-    // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost
-    // more than the separate statistics pass they replace); nbdt_bn_finalize folds the rows
-    // (the fold kernels expect one row per 256 pixels: a 512-pixel tile fills row 2*m_blk and zeroes the next)
     constexpr int RPB = NWV / 4;
+    // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost more than the
+    // separate statistics pass they replace); nbdt_bn_finalize folds the rows
+    // (the fold kernels expect one row per 256 pixels: a 512-pixel tile fills row 2*m_blk and zeroes the next)
     float* part = p.stats + (size_t)m_blk * RPB * 2 * d.cout;
     const bool second = RPB == 2 && (m_blk * RPB + 1) * 256 < p.M;
-    for (int i = tid; i < 2 * BN; i += NTHR) {
-      const int which = i / BN, c = i - which * BN;
-      part[(size_t)which * d.cout + n0 + c] = blk_stats[i];
-      if (second) part[(size_t)(2 + which) * d.cout + n0 + c] = 0.f;
+    if (STATS_VIA_REGIONS) {
+      if (walker) {      // this lane's 16 partials -> [rl][ch][16 floats] at the start of the wave's own region
+        float* mine = (float*)region + (rl * NCH + ch) * 16;
+        *(float4*)(mine + 0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *(float4*)(mine + 4) = make_float4(s1[4], s1[5], s1[6], s1[7]);
+        *(float4*)(mine + 8) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        *(float4*)(mine + 12) = make_float4(s2[4], s2[5], s2[6], s2[7]);
+      }
+      __syncthreads();   // (also: every wave's row walk has read its region before anybody's partials land in it --
+                         //  a wave only writes its OWN region, after its own walk)
+      for (int i = tid; i < 2 * BN; i += NTHR) {
+        const int which = i / BN, c = i - which * BN;
+        const int off = ((c >> 3) * 16 + which * 8 + (c & 7)) * 4;      // byte offset inside an [rl] slab
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+          const unsigned char* rg = w < lds.n_a ? lds.base_a + w * REGION_BYTES : lds.base_b + (w - lds.n_a) * REGION_BYTES;
+#pragma unroll
+          for (int r = 0; r < RL; ++r) sum += *(const float*)(rg + r * (NCH * 64) + off);
+        }
+        part[(size_t)which * d.cout + n0 + c] = sum;
+        if (second) part[(size_t)(2 + which) * d.cout + n0 + c] = 0.f;
+      }
+    } else {
+      if (p.deterministic) {
+        // fixed order: wave 0's row lanes 0, 1, ..., then wave 1's, ... -- one turn per barrier, plain read-modify-write
+        // (lanes of one turn hold distinct channel chunks).  NWV * RL barriers per tile: a debugging mode, not a fast one.
+        for (int w = 0; w < NWV; ++w)
+          for (int r = 0; r < RL; ++r) {
+            if (wave == w && walker && rl == r)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                blk_stats[ch * 8 + i] += s1[i];
+                blk_stats[BN + ch * 8 + i] += s2[i];
+              }
+            __syncthreads();
+          }
+      } else {
+        if (walker)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            atomicAdd(blk_stats + ch * 8 + i, s1[i]);
+            atomicAdd(blk_stats + BN + ch * 8 + i, s2[i]);
+          }
+        __syncthreads();
+      }
+      for (int i = tid; i < 2 * BN; i += NTHR) {
+        const int which = i / BN, c = i - which * BN;
+        part[(size_t)which * d.cout + n0 + c] = blk_stats[i];
+        if (second) part[(size_t)(2 + which) * d.cout + n0 + c] = 0.f;
+      }
     }
   }
 }

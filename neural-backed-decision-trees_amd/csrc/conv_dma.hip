@@ -98,8 +98,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const nbdt::ConvDmaParams& p
 #pragma unroll
     for (int k = 0; k < IPW_W; ++k) {
       const int id = ((wave + 2) & 3) + 4 * k;
-      if (id < W_INSTR)  // wave-uniform
+      if (id < W_INSTR) {  // wave-uniform
+#ifdef NBDT_DMA_WTILED_FAKE   // timing experiment: what DMA-ordered weight tiles (one contiguous KiB per piece) would buy
+        glds16(w_base + (((kc * ntaps + tap) * W_INSTR + id) * 512 + lane * 8),
+               __builtin_amdgcn_readfirstlane(dst0 + A_BYTES + id * 1024));
+#else
         glds16(w_base + (w_src[k] + w_k), __builtin_amdgcn_readfirstlane(dst0 + A_BYTES + id * 1024));
+#endif
+      }
     }
   };
 

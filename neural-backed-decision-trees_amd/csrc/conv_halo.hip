@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     epi_lds.region = wave < in_a1 ? smem + a_bytes + wave * EPI_REGION : tail + (wave - in_a1) * EPI_REGION;
     epi_lds.row_off = (int*)(tail + n_tail * EPI_REGION) + wave * 64;
     epi_lds.blk_stats = (float*)(tail + n_tail * EPI_REGION + NWV * 64 * 4);
+    epi_lds.base_a = smem + a_bytes; epi_lds.base_b = tail; epi_lds.n_a = in_a1 < NWV ? in_a1 : NWV;
   }
 
   issue_first(cur);

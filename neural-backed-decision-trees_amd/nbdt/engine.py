@@ -275,6 +275,7 @@ class _Engine:
         self.debug_join_each_unit = False # A/B: join the side stream at the top of every unit (the schedule before round 3)
         self.fuse_stats = True    # BN sums come out of the producing conv's epilogue (no stats pass)
         self.fuse_eval = True     # inference: eval-mode BN + activation folded into the conv epilogue
+        self.share_bn2_tensors, self.share_bn1_tensors = 5, 6   # tensor passes of the confined BatchNorm backward (CU plan)
         self.fuse_bn_fold = True  # CU-confined BatchNorm backward: fold of the sums inside the elementwise pass (2 launches)
         self.fuse_dw_bn_bwd = True  # MBConv: BatchNorm-backward sums in the depthwise data gradient's epilogue (A/B)
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
@@ -870,7 +871,7 @@ class WRNEngine(_Engine):
                 fuse = False
             if split:
                 u["conv2"].backward_data(g, ga2)
-                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 5, self._share_split[1])
+                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, self.share_bn2_tensors, self._share_split[1])
                 u["bn2"].backward_cus(ga2, t, gt, n2)
                 if self._share_join:
                     self.join_side_stream()
@@ -894,7 +895,7 @@ class WRNEngine(_Engine):
             if split and u["idconv"] is None:
                 x_in = u["x_in"]
                 u["conv1"].backward_data(gt, ga1)
-                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 6, self._share_split[1])
+                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, self.share_bn1_tensors, self._share_split[1])
                 u["bn1"].backward_cus(ga1, x_in, g_in, n1, gx_add=g)
                 g, h, w = g_in, hi, wi
                 continue

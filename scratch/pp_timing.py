@@ -11,7 +11,11 @@ for (B, H, C) in [(512, 32, 160), (512, 8, 640), (8, 32, 160)]:
     out = ops.padded(B, H, H, C, DEV)
     d = ops.conv_fwd_desc(B, H, H, C, C, 3, 1); d.wide_tile = 2
     wt = ops.weight_tiles(w); d.w_tiled = wt.data_ptr()
-    for _ in range(3): ops.conv_igemm(d, x, w, out)
+    stats = torch.zeros(((B * H * H + 255) // 256) * 2 * C, device=DEV) if os.environ.get("STATS") else None
+    res = None
+    if os.environ.get("RES"):
+        res = ops.padded(B, H, H, C, DEV); ops.interior(res).normal_()
+    for _ in range(3): ops.conv_igemm(d, x, w, out, residual=res, bn_scratch=stats)
     torch.cuda.synchronize()
     buf = np.zeros(8192 * 8, dtype=np.uint32)
     lib = _C.lib()
@@ -23,7 +27,7 @@ for (B, H, C) in [(512, 32, 160), (512, 8, 640), (8, 32, 160)]:
     steps = t[:, 5].mean()
     names = ["load-seg", "barrier1", "mfma-seg", "barrier2", "total", "steps", "epilogue"]
     for g, sel in (("group0", np.arange(len(t)) % 8 < 4), ("group1", np.arange(len(t)) % 8 >= 4)):
-        print(f"B={B} H={H} C={C} {g}: " + "  ".join(f"{n} {t[sel, i].mean() / (steps if i < 5 else 1):7.1f}" for i, n in enumerate(names)) + f"  (cycles/step, {int(steps)} steps, rc {rc})")
+        print(f"B={B} H={H} C={C} stats={stats is not None} res={res is not None} {g}: " + "  ".join(f"{n} {t[sel, i].mean() / (steps if i < 5 else 1):7.1f}" for i, n in enumerate(names)) + f"  (cycles/step, {int(steps)} steps, rc {rc})")
     e = np.zeros(8192 * 8, dtype=np.uint32)
     lib.nbdt_debug_pp_epi.restype = ctypes.c_int
     lib.nbdt_debug_pp_epi(e.ctypes.data_as(ctypes.c_void_p))

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(1024) void bn_fold_partials_kernel(const float* __r
                                                                 float* __restrict__ save_mean,
                                                                 float* __restrict__ save_rstd) {
   constexpr int RL = 1024 / CL;
-  __shared__ float red[2][RL][CL + 1];
+  static_assert(CL <= 32 && 64 % CL == 0, "a wave holds whole groups of CL channels");
+  __shared__ float red[2][16][CL + 1];
   const int cl = threadIdx.x % CL, rs = threadIdx.x / CL;
   const int c = blockIdx.x * CL + cl;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
@@ -560,12 +561,21 @@ __global__ __launch_bounds__(1024) void bn_fold_partials_kernel(const float* __r
       q0 += part[((size_t)r * 2 + 1) * C + c];
     }
   }
-  red[0][rs][cl] = (s0 + s1) + (s2 + s3);
-  red[1][rs][cl] = (q0 + q1) + (q2 + q3);
+  // row lanes -> one value per channel: butterfly over the lanes of a wave that hold the same channel (lane bits
+  // >= log2 CL), then the 16 waves' values through LDS
+  float ws = (s0 + s1) + (s2 + s3), wq = (q0 + q1) + (q2 + q3);
+#pragma unroll
+  for (int off = CL; off < 64; off <<= 1) {
+    ws += __shfl_xor(ws, off, 64);
+    wq += __shfl_xor(wq, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < CL) { red[0][wave][lane] = ws; red[1][wave][lane] = wq; }
   __syncthreads();
-  if (rs == 0 && c < C) {
+  if (rs == 0 && c < C) {      // (rs == 0: threads 0 .. CL-1, cl == threadIdx.x)
     float s = 0.f, sq = 0.f;
-    for (int k = 0; k < RL; ++k) { s += red[0][k][cl]; sq += red[1][k][cl]; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; sq += red[1][k][cl]; }
     const float mean = s / n;
     float var = sq / n - mean * mean;
     var = var > 0.f ? var : 0.f;

@@ -604,6 +604,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
     // ---- epilogue: acc[t][a][r]: co = co0 + (wm*WM + a)*16 + 4*g4 + r ; ci = ci0 + wn*16 + t16
     if (grp == 0) __builtin_amdgcn_s_barrier();
     const int ci = ci0 + wn * 16 + t16;
+#ifdef NBDT_WPP_NO_EPI       // timing experiment: what the fp32 atomics of the epilogue cost (accumulators stay live)
+    float keep = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t)
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep += acc[t][a][r];
+    if (keep == 12345.678f) p.dw[ci] = keep;
+#else
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
       const int w_tap = d.w_tap[T0 + t];
@@ -615,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
           atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
         }
     }
+#endif
   };
   if (grp == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, NT0>{});
   else run(std::integral_constant<int, NT0>{}, std::integral_constant<int, 9 - NT0>{});

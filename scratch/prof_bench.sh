@@ -7,7 +7,7 @@ TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 cd /tmp
-B="python $R/bench.py --no-cpu-baseline --no-kernel-timer --agreement-n 0 --no-other-configs"
+B="python $R/bench.py --no-cpu-baseline --no-kernel-timer --agreement-n 0 --no-other-configs --cu-share-force"
 # per-kernel durations that must agree with bench.py's roofline pass: single stream (no concurrent kernel)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $B --steps 5 --warmup 2 --no-overlap > $OUT/trace.log 2>&1
 # the default (weight gradients on the second stream): kernel durations overlap

@@ -581,9 +581,11 @@ extern "C" int nbdt_bn_stats(const void* x, int32_t B, int32_t H, int32_t W, int
 
 // fold [rows][2][C] partial sums written by conv epilogues: block = CL channels x (1024 / CL) row lanes, every
 // thread keeps 4 independent loads in flight (a 5-block, 8-row-lane version took 39 us at 2048 rows).
-// CL = 32: 32 row lanes (short tables).  CL = 8: 128 row lanes and four times the blocks -- a 2048-row table of a
-// 32x32x160 layer is 2.6 MB, and 5 blocks (= 5 CUs) took 14 us to pull it through their L2 ports on the forward
-// pass's critical path; 20 blocks take 6.  Same summation tree for a given (rows, CL): deterministic.
+// CL = 32: 32 row lanes (short tables).  CL = 8: 128 row lanes and four times the blocks for tall tables (2048 rows of
+// a 32x32x160 layer = 2.6 MB).  Round 4 measured what this kernel's 11-13 us after such a conv are: NOT its structure
+// (5 or 20 or 40 blocks, 8 or 16 loads in flight, serial or butterfly row reduction: all the same) but the kernel
+// boundary writing back the 168 MB the conv left dirty in the L2s -- whichever kernel comes next pays it.
+// Same summation tree for a given (rows, CL): deterministic.
 template <int CL>
 __global__ __launch_bounds__(1024) void bn_fold_partials_kernel(const float* __restrict__ part, int rows, int C,
                                                                 float n, float eps, float momentum,

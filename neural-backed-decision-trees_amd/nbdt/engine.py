@@ -419,7 +419,7 @@ class _Engine:
         """Decide whether the CU-sharing schedule set by set_cu_share() is kept on THIS box: time the conv2 half of one
         widest-tensor unit -- data gradient, BatchNorm backward, weight gradient, exactly the launches backward()
         would make -- in the default order and in the sharing order that is configured (split or fused sums), each
-        4 times on the engine's own buffers (about 3 ms, once), and keep the sharing only if it is at least 9 %
+        4 times on the engine's own buffers (about 3 ms, once), and keep the sharing only if it is at least 6 %
         faster (the pair-to-step fit in the code below).  Needs a training-mode forward() at the batch size that will be trained (it uses that forward's
         activations and BatchNorm statistics); backward() calls it before its first launch when a new setting has not
         been calibrated yet.  It synchronises with the host, so it must not run inside a hipGraph capture (GraphedStep
@@ -505,10 +505,12 @@ class _Engine:
 
         t_default, t_share = best_us(default_order), best_us(sharing_order)
         # The isolated pair overstates what the whole step gains: in the default order a weight gradient already hides
-        # under the NEXT data gradient, which one pair cannot show.  Measured on WRN-28-10 (scratch/share_by_batch.py,
-        # profiles/r03_share_by_batch.txt): pair 4.8 % faster -> step 1.8 % SLOWER (256 images); 12.4 % -> +0.9 % (384);
-        # 21 % -> +7.7 % (512) -- break-even near 8 %, so the sharing is kept from 9 % up.
-        keep = t_share < 0.91 * t_default
+        # under the NEXT data gradient, which one pair cannot show.  Measured on WRN-28-10 (scratch/share_by_batch.py;
+        # round 4, after the epilogue statistics stopped costing the default order's data gradients 40 us each:
+        # profiles/r04_share_by_batch.txt): pair 4.7 % SLOWER -> step 10 % slower (128 images); pair 8-10 % faster ->
+        # step +2.7 ... +3.7 % (256); 18 % -> +5.7 % (384); 29 % -> +12.7 % (512) -- break-even near 5 %, so the
+        # sharing is kept from 6 % up (round 3's data put the break-even at 8 %).
+        keep = t_share < 0.94 * t_default
         decided_by = "this rank"
         if comm is not None and comm.world_size > 1:
             keep = comm.broadcast_flag(keep, self.device)

@@ -91,95 +91,127 @@ extern "C" int nbdt_set_reserved_cus(int32_t n) {
 extern "C" int nbdt_get_reserved_cus(void) { return nbdt::reserved_cus(); }
 
 // ------------------------------------------------------------------------------------------ stem
-// thread = (pixel, 8-cout chunk); weights [cout][3][3][3] (co, r, s, ci) staged in LDS
+// thread = one output pixel: its 27 image values stay in registers and every 8-cout chunk re-uses them; the weights sit
+// in LDS as [tap][cout], so a chunk's 8 weights of a tap are two broadcast ds_read_b128.  (Round 1's form -- one thread
+// per (pixel, 8-cout chunk), 216 ds_read_b32 and 27 global loads each -- took 55 us for the 16-channel WRN stem at 512
+// images and 115 us for ResNet18's 64-channel stem at 128 x 64x64.)
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         int B, int H, int W, int cout, int cpad, int stride,
                                                         bf16_t* __restrict__ out) {
-  extern __shared__ float wl[];  // [cout][27]
-  for (int i = threadIdx.x; i < cout * 27; i += 256) wl[i] = w[i];
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [27][cout]
+  for (int i = threadIdx.x; i < cout * 27; i += 256) {
+    const int co = i / 27, t = i - co * 27;
+    wl[t * cout + co] = w[i];
+  }
   __syncthreads();
-  const int chunks = cout / 8;
   const int Ho = H / stride, Wo = W / stride;   // H, W: image size; output is Ho x Wo
-  const long long total = (long long)B * Ho * Wo * chunks;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int ck = (int)(idx % chunks);
-  const int p = (int)(idx / chunks);
-  const int x = p % Wo, y = (p / Wo) % Ho, b = p / (Wo * Ho);
-  float acc[8];
+  const long long total = (long long)B * Ho * Wo;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= total) return;
+  const int x = (int)(p % Wo), y = (int)((p / Wo) % Ho), b = (int)(p / ((long long)Wo * Ho));
+  float v[27];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   for (int r = 0; r < 3; ++r) {
     const int yy = y * stride + r - 1;
-    if (yy < 0 || yy >= H) continue;
+#pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int xx = x * stride + s - 1;
-      if (xx < 0 || xx >= W) continue;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci) {
-        const float v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += v * wl[(ck * 8 + i) * 27 + (r * 3 + s) * 3 + ci];
-      }
+      for (int ci = 0; ci < 3; ++ci)
+        v[(r * 3 + s) * 3 + ci] = in ? img[(((size_t)b * 3 + ci) * H + yy) * W + xx] : 0.f;
     }
   }
-  const size_t o = (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + ck * 8;
-  *(u32x4_t*)(out + o) = pack8(acc);
+  bf16_t* o = out + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad;
+  for (int ck = 0; ck < cout / 8; ++ck) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const float4 w0 = *(const float4*)(wl + t * cout + ck * 8);
+      const float4 w1 = *(const float4*)(wl + t * cout + ck * 8 + 4);
+      acc[0] += v[t] * w0.x; acc[1] += v[t] * w0.y; acc[2] += v[t] * w0.z; acc[3] += v[t] * w0.w;
+      acc[4] += v[t] * w1.x; acc[5] += v[t] * w1.y; acc[6] += v[t] * w1.z; acc[7] += v[t] * w1.w;
+    }
+    *(u32x4_t*)(o + ck * 8) = pack8(acc);
+  }
 }
 
-// dw[co][27] += sum_pixels gy[pix][co] * img[tap]; block = pixel range, 64-pixel tiles in LDS
+// dw[co][27] += sum_pixels gy[pix][co] * img[tap]: per 64-pixel tile the gy tile [64][cout] and the patch tile
+// [64][28] go to LDS (a thread owns one pixel of the tile for both loads: one (b, y, x) decomposition per tile, 16-byte
+// bf16 loads of gy), then thread (k, co quad) accumulates 4 outputs with one ds_read_b32 + one ds_read_b128 per pixel.
+// (Round 1's form decomposed the pixel index for every ELEMENT it loaded and read two LDS words per multiply-add:
+// 100 us for the WRN stem at 512 images, 210 us for ResNet18's at 128 x 64x64.)
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gy,
                                                          int B, int H, int W, int cout, int cpad, int stride,
                                                          int tiles_per_block, float* __restrict__ dw,
                                                          int row_stride) {
   // row_stride: 0 = every block adds into dw; deterministic mode: cout*27, a zeroed row per block (det_fold sums them)
-  extern __shared__ float lds[];  // gy tile [64][cout] then patch tile [64][27]
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // gy tile [64][cout] then patch tile [64][28]
   float* gl = lds;
   float* pl = lds + 64 * cout;
   const int Ho = H / stride, Wo = W / stride;
   const int npix = B * Ho * Wo;
-  const int nout = cout * 27;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // outputs tid, tid+256, ... (<= 2048)
+  const int nq = cout / 4;                     // co quads
+  const int nwork = nq * 27;                   // (quad, k) pairs, each 4 outputs
+  constexpr int MAXW = 2;                      // pairs per thread: nwork <= 512, i.e. cout <= 72 (host checks cout*27 <= 2048)
+  float acc[MAXW][4];
+#pragma unroll
+  for (int j = 0; j < MAXW; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+  // loader roles: thread -> (pixel of the tile, part): parts 0..c8-1 load 8 gy channels each, the others patch values
+  const int c8 = cout / 8;
+  const int lp = threadIdx.x & 63, part = threadIdx.x >> 6;      // 4 parts per pixel
   for (int t = 0; t < tiles_per_block; ++t) {
     const int p0 = (blockIdx.x * tiles_per_block + t) * 64;
     if (p0 >= npix) break;
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * cout; i += 256) {
-      const int pp = p0 + i / cout, co = i % cout;
-      float v = 0.f;
-      if (pp < npix) {
-        const int x = pp % Wo, y = (pp / Wo) % Ho, b = pp / (Wo * Ho);
-        v = bf16_to_f32(gy[(((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + co]);
+    {
+      const int pp = p0 + lp;
+      const bool live = pp < npix;
+      const int x = pp % Wo, y = (pp / Wo) % Ho, b = pp / (Wo * Ho);
+      // gy: chunks part, part+4, ... of this pixel
+      for (int ck = part; ck < c8; ck += 4) {
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) unpack8(*(const u32x4_t*)(gy + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + ck * 8), f);
+        *(float4*)(gl + lp * cout + ck * 8) = make_float4(f[0], f[1], f[2], f[3]);
+        *(float4*)(gl + lp * cout + ck * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
       }
-      gl[i] = v;
-    }
-    for (int i = threadIdx.x; i < 64 * 27; i += 256) {
-      const int pp = p0 + i / 27, k = i % 27;
-      float v = 0.f;
-      if (pp < npix) {
-        const int x = pp % Wo, y = (pp / Wo) % Ho, b = pp / (Wo * Ho);
+      // patch: taps part, part+4, ... (27 values per pixel, row pitch 28)
+      for (int k = part; k < 27; k += 4) {
         const int r = k / 9, s = (k / 3) % 3, ci = k % 3;
         const int yy = y * stride + r - 1, xx = x * stride + s - 1;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
+        float v = 0.f;
+        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
+        pl[lp * 28 + k] = v;
       }
-      pl[i] = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int o = threadIdx.x + 256 * q;
-      if (o < nout) {
-        const int co = o / 27, k = o % 27;
-        float s = 0.f;
-        for (int pp = 0; pp < 64; ++pp) s += gl[pp * cout + co] * pl[pp * 27 + k];
-        acc[q] += s;
+    for (int j = 0; j < MAXW; ++j) {
+      const int o = threadIdx.x + 256 * j;
+      if (o < nwork) {
+        const int q = o / 27, k = o - q * 27;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+        for (int pp = 0; pp < 64; ++pp) {
+          const float pv = pl[pp * 28 + k];
+          const float4 g = *(const float4*)(gl + pp * cout + q * 4);
+          a0 += g.x * pv; a1 += g.y * pv; a2 += g.z * pv; a3 += g.w * pv;
+        }
+        acc[j][0] += a0; acc[j][1] += a1; acc[j][2] += a2; acc[j][3] += a3;
       }
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int o = threadIdx.x + 256 * q;
-    if (o < nout) atomicAdd(dw + (size_t)blockIdx.x * row_stride + o, acc[q]);
+  for (int j = 0; j < MAXW; ++j) {
+    const int o = threadIdx.x + 256 * j;
+    if (o < nwork) {
+      const int q = o / 27, k = o - q * 27;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        atomicAdd(dw + (size_t)blockIdx.x * row_stride + (q * 4 + i) * 27 + k, acc[j][i]);
+    }
   }
 }
 
@@ -189,7 +221,7 @@ extern "C" int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32
   NBDT_REQUIRE(B > 0 && H > 0 && W > 0, "empty image batch");
   NBDT_REQUIRE((stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0, "bad stem stride");
   NBDT_REQUIRE(cout_real > 0 && cout_real % 8 == 0 && cout_real <= cpad && cpad % 8 == 0, "bad stem channels");
-  const long long total = (long long)B * (H / stride) * (W / stride) * (cout_real / 8);
+  const long long total = (long long)B * (H / stride) * (W / stride);      // one thread per output pixel
   hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), cout_real * 27 * sizeof(float),
                      (hipStream_t)stream, img, w, B, H, W, cout_real, cpad, stride, (bf16_t*)out);
   NBDT_LAUNCH_CHECK();
@@ -200,13 +232,14 @@ extern "C" int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int3
                                int32_t cpad, int32_t stride, float* dw, void* stream) {
   NBDT_REQUIRE(img && gy && dw, "null argument");
   NBDT_REQUIRE((stride == 1 || stride == 2) && H % stride == 0 && W % stride == 0, "bad stem stride");
-  NBDT_REQUIRE(cout_real > 0 && cout_real * 27 <= 2048 && cout_real <= cpad, "stem wgrad supports cout <= 75");
+  NBDT_REQUIRE(cout_real > 0 && cout_real % 8 == 0 && cout_real <= 72 && cout_real <= cpad,
+               "stem wgrad supports cout = 8, 16, ..., 72");
   const int npix = B * (H / stride) * (W / stride);
   const int tiles = (npix + 63) / 64;
   int blocks = tiles < 1024 ? tiles : 1024;
   const int tpb = (tiles + blocks - 1) / blocks;
   blocks = (tiles + tpb - 1) / tpb;
-  const size_t shmem = (size_t)(64 * cout_real + 64 * 27) * sizeof(float);
+  const size_t shmem = (size_t)(64 * cout_real + 64 * 28) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const int nout = cout_real * 27;
   float* target = dw;

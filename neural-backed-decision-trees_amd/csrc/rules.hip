@@ -717,6 +717,9 @@ __global__ __launch_bounds__(block_of(TPS)) void soft_loss_kernel(TreeView t, co
 //     dpooled[b][k] = sum_c gz[c] W[c][k]              (ascending c, fused multiply-adds: linear_bwd_x_kernel's order)
 //     dW[c][k] += sum over the block's SPB samples of gz[c] x[k],  db[c] += sum of gz[c]   (one add per block and
 //     address; deterministic mode: a zeroed row per block, summed in block order by det_fold).
+#ifndef NBDT_HEAD_SKIP
+#define NBDT_HEAD_SKIP 0     // timing-only builds: bit 0 drops the forward, 1 the dpooled, 2 the dW / db phase
+#endif
 template <int TPS, int SPB>
 __global__ __launch_bounds__(TPS * SPB) void head_soft_loss_kernel(TreeView t, const float* __restrict__ pooled,
                                                                    const float* __restrict__ W,
@@ -746,45 +749,113 @@ __global__ __launch_bounds__(TPS * SPB) void head_soft_loss_kernel(TreeView t, c
   if (active)
     for (int k = g_tid; k < K; k += TPS) xs[k] = pooled[sample * K + k];
   __syncthreads();
-  {  // classifier forward: wave wv of the group takes classes wv, wv + NW, ...
-    constexpr int NW = TPS / 64;
-    const int wv = g_tid >> 6, lane = g_tid & 63;
-    if (active)
-      for (int c = wv; c < t.C; c += NW) {
-        const float* wr = W + (size_t)c * K;
-        float s = 0.f;
-        for (int k = lane; k < K; k += 64) s = fmaf(xs[k], wr[k], s);
+  const int n_live = (int)((B - (int64_t)blockIdx.x * SPB) < SPB ? (B - (int64_t)blockIdx.x * SPB) : SPB);
+#if !(NBDT_HEAD_SKIP & 1)
+  {  // classifier forward, the whole block together: wave wv takes classes wv, wv + NWB, ... FOUR at a time, and forms
+     // their inner products for ALL the block's samples from one read of the W rows (4 rows x 8 x 64 features in
+     // registers, so 32 loads per lane are in flight together; a row used to be re-read per sample, one dependent load
+     // at a time).  Every (sample, class) sum keeps linear_fwd_kernel's order: lanes stride the features, fused
+     // multiply-adds in ascending k, xor-butterfly.
+    constexpr int NWB = TPS * SPB / 64, CU = 4;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int zs_off = (int)(zs - xs);
+    for (int c0 = wv; c0 < t.C; c0 += NWB * CU) {
+      float s[CU][SPB];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) {
-          const float zc = s + (bias ? bias[c] : 0.f);
-          zs[c] = zc;
-          if (z_out) z_out[sample * t.C + c] = zc;
+      for (int u = 0; u < CU; ++u)
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) s[u][j] = 0.f;
+      for (int k0 = lane; k0 < K; k0 += 512) {
+        float w[CU][8];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+          const int c = c0 + u * NWB;
+          const float* wr = W + (size_t)(c < t.C ? c : c0) * K;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) w[u][i] = k0 + i * 64 < K ? wr[k0 + i * 64] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (k0 + i * 64 < K) {
+            float x[SPB];
+#pragma unroll
+            for (int j = 0; j < SPB; ++j) x[j] = rows[(size_t)j * stride + k0 + i * 64];
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+#pragma unroll
+              for (int j = 0; j < SPB; ++j) s[u][j] = fmaf(x[j], w[u][i], s[u][j]);
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < CU; ++u)
+#pragma unroll
+        for (int j = 0; j < SPB; ++j) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) s[u][j] += __shfl_xor(s[u][j], off, 64);
+        }
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+          const int c = c0 + u * NWB;
+          if (c < t.C) {
+            const float bc = bias ? bias[c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < SPB; ++j)
+              if (j < n_live) {
+                const float zc = s[u][j] + bc;
+                rows[(size_t)j * stride + zs_off + c] = zc;
+                if (z_out) z_out[((int64_t)blockIdx.x * SPB + j) * t.C + c] = zc;
+              }
+          }
         }
       }
+    }
   }
+#endif
   __syncthreads();
   soft_loss_from_lds_logits<TPS>(t, o, active, g_tid, sample, y, w_x, w_t, scale, row_loss, zs, ss, ps, pq, gx, red,
                                  stage, ga, gbk, nullptr);
   __syncthreads();      // every sample's gx is complete: the block-wide weight-gradient sums read all of them
-  if (active && gpooled)
-    for (int k = g_tid; k < K; k += TPS) {
-      float s = 0.f;
-      for (int c = 0; c < t.C; ++c) s = fmaf(gx[c], W[(size_t)c * K + k], s);
-      gpooled[sample * K + k] = s;
+#if !(NBDT_HEAD_SKIP & 2)
+  if (gpooled) {      // thread = feature k for ALL the block's samples: one read of W's column per block, 32 rows in flight;
+    const int gx_off = (int)(gx - xs);      // each (sample, k) sum stays one ascending chain of fused multiply-adds
+    for (int k = threadIdx.x; k < K; k += TPS * SPB) {
+      float s[SPB];
+#pragma unroll
+      for (int j = 0; j < SPB; ++j) s[j] = 0.f;
+      for (int c0 = 0; c0 < t.C; c0 += 32) {
+        float w[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w[i] = c0 + i < t.C ? W[(size_t)(c0 + i) * K + k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+          if (c0 + i < t.C) {
+#pragma unroll
+            for (int j = 0; j < SPB; ++j) s[j] = fmaf(rows[(size_t)j * stride + gx_off + c0 + i], w[i], s[j]);
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < SPB; ++j)
+        if (j < n_live) gpooled[((int64_t)blockIdx.x * SPB + j) * K + k] = s[j];
     }
+  }
+#endif
+#if !(NBDT_HEAD_SKIP & 4)
   if (gW) {
-    const int n_live = (int)((B - (int64_t)blockIdx.x * SPB) < SPB ? (B - (int64_t)blockIdx.x * SPB) : SPB);
     const int gx_off = (int)(gx - xs);
     float* dw = gW + (size_t)blockIdx.x * row_stride_w;
-    for (int idx = threadIdx.x; idx < t.C * K; idx += TPS * SPB) {
-      const int c = idx / K, k = idx - c * K;
+    constexpr int NT = TPS * SPB;
+    const int dc = NT / K, dk = NT - dc * K;        // idx += NT as (c, k) += (dc, dk) with a carry: no division per element
+    int c = threadIdx.x / K, k = threadIdx.x - c * K;
+    for (int idx = threadIdx.x; idx < t.C * K; idx += NT) {
       float s = 0.f;
       for (int j = 0; j < n_live; ++j) {
         const float* xr = rows + (size_t)j * stride;
         s = fmaf(xr[gx_off + c], xr[k], s);
       }
       atomicAdd(dw + idx, s);
+      c += dc; k += dk;
+      if (k >= K) { k -= K; ++c; }
     }
     if (gb) {
       float* db = gb + (size_t)blockIdx.x * row_stride_b;
@@ -795,6 +866,7 @@ __global__ __launch_bounds__(TPS * SPB) void head_soft_loss_kernel(TreeView t, c
       }
     }
   }
+#endif
 }
 
 // HardTreeSupLoss forward+backward for criterion = nn.CrossEntropyLoss() (nbdt/loss.py:212-257):
@@ -1328,7 +1400,13 @@ extern "C" int nbdt_head_soft_tree_loss(const nbdt_tree* t, const float* pooled,
   // samples per block: 8 for one-wave groups (16 / 8 / 4 measure the same inside the training step, 8 is the fastest
   // alone: profiles/r03_head.txt), fewer if the hierarchy's LDS rows do not fit
   if (tps == 64) { NBDT_HEAD(64, 8); NBDT_HEAD(64, 4); NBDT_HEAD(64, 1); }
+#if defined(NBDT_HEAD_SPB) && NBDT_HEAD_SPB == 2
+  else { NBDT_HEAD(256, 2); NBDT_HEAD(256, 1); }
+#elif defined(NBDT_HEAD_SPB) && NBDT_HEAD_SPB == 1
+  else { NBDT_HEAD(256, 1); }
+#else
   else { NBDT_HEAD(256, 4); NBDT_HEAD(256, 2); NBDT_HEAD(256, 1); }
+#endif
 #undef NBDT_HEAD
   NBDT_REQUIRE(rc != 1, "hierarchy + feature row too large for LDS");
   if (rc) return rc;

@@ -278,6 +278,7 @@ class _Engine:
         self.share_bn2_tensors, self.share_bn1_tensors = 5, 6   # tensor passes of the confined BatchNorm backward (CU plan)
         self.fuse_bn_fold = True  # CU-confined BatchNorm backward: fold of the sums inside the elementwise pass (2 launches)
         self.fuse_dw_bn_bwd = True  # MBConv: BatchNorm-backward sums in the depthwise data gradient's epilogue (A/B)
+        self.fuse_bn1_bwd = True  # ResNet basic block: bn1's backward sums in conv2's data-gradient epilogue (A/B)
         self._side = None         # second stream for weight gradients (WRNEngine turns it on)
         self._cu_share = None     # set_cu_share(): BatchNorm-backward passes beside weight gradients on disjoint CUs
         self._share_join = False
@@ -1117,8 +1118,14 @@ class ResNetEngine(_Engine):
                 # identity shortcut: the masked gradient IS part of the block-input gradient
                 blk["bn2"].backward(g, out, t2, gt2, relu=True, g_resid=g_in)
             blk["conv2"].backward_weight(a1, gt2)
-            blk["conv2"].backward_data(gt2, ga1)
-            blk["bn1"].backward(ga1, None, t1, gt1, relu=True)
+            if self.fuse_bn1_bwd and self.act_dtype == torch.bfloat16:
+                # conv2's data gradient is dL/d(relu(bn1(t1))): its epilogue also emits bn1's backward sums (as in
+                # WRNEngine's fused order), so ga1 is not re-read for them -- one HBM-bound pass fewer per block
+                blk["conv2"].backward_data(gt2, ga1, bn=blk["bn1"], bn_x=t1, partials=self.partials(t1))
+                blk["bn1"].backward_fused(ga1, t1, gt1, self.partials(t1))
+            else:
+                blk["conv2"].backward_data(gt2, ga1)
+                blk["bn1"].backward(ga1, None, t1, gt1, relu=True)
             blk["conv1"].backward_weight(x_in, gt1)
             if blk["sconv"] is not None:
                 blk["conv1"].backward_data(gt1, g_in)
@@ -1216,7 +1223,12 @@ class GraphedStep:
                                "build a new GraphedStep (they are baked into the captured launches)")
         self.img.copy_(img, non_blocking=True)
         self.targets.copy_(targets, non_blocking=True)
+        # the captured step holds no gradient fill when it was captured after a step whose SGD pass left the buffer
+        # zeroed (zero_grad() was free then): anything eager that accumulated since must be cleared here, not summed in
+        if not getattr(self.engine, "_grad_is_zero", False):
+            self.engine.store.zero_grad()
         self.graph.replay()
+        self.engine._grad_is_zero = True     # the replayed SGD pass zeroed it again
         return self.loss
 
 

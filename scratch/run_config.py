@@ -17,6 +17,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--one-stream", action="store_true")
+ap.add_argument("--set", action="append", default=[], help="engine attribute override, e.g. fuse_bn1_bwd=0")
 a = ap.parse_args()
 DEV = "cuda:0"
 CASES = {   # engine factory, dataset, hierarchy, batch, image size, classes, tree-supervision weight
@@ -36,6 +37,10 @@ if a.batch:
 eng = mk()
 if a.one_stream:
     eng.set_overlap(False)
+for kv in a.set:
+    k, v = kv.split("=")
+    assert hasattr(eng, k), k
+    setattr(eng, k, type(getattr(eng, k))(int(v)))
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, 3, size, size, generator=g).to(DEV)
 y = torch.randint(0, C, (B,), generator=g).to(DEV)

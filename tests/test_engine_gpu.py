@@ -18,6 +18,7 @@ import torch_models as TM
 pytestmark = pytest.mark.gpu
 
 from nbdt import engine as E  # noqa: E402
+from nbdt import ops  # noqa: E402
 from nbdt.loss import SoftTreeSupLoss  # noqa: E402
 
 DEV = "cuda:0"
@@ -463,6 +464,38 @@ def test_hipgraph_captured_step_equals_eager_steps():
     assert losses[-1] < losses[0] and (graphed.store.flat - before).norm().item() > 0
 
 
+def test_hipgraph_replay_does_not_sum_onto_gradients_an_eager_call_left_behind():
+    """A step captured after a step whose SGD pass zeroed the gradient buffer contains no fill of its own.  An eager
+    forward / loss / backward between two replays (no optimizer step) leaves the batch's gradient in the buffer: the
+    next replay must clear it first.  With momentum 0 and weight decay 0 a replay moves the parameters by lr x
+    gradient; on a small lr two consecutive replays of one batch move them by nearly the same vector, while a replay
+    that summed onto the stale gradient of the same batch would move them by TWICE that."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (16,), generator=g).to(DEV)
+    eng = E.ResNetEngine(num_classes=10, device=DEV, seed=4)
+    step = E.GraphedStep(eng, crit, x, y, lr=1e-4, momentum=0.0, weight_decay=0.0, warmup=1)
+    p0 = eng.store.flat.clone()
+    step(x, y)
+    torch.cuda.synchronize()
+    p1 = eng.store.flat.clone()
+    z = eng.forward(x, training=True)                   # eager gradients, never consumed by an optimizer step
+    _, gz = crit.loss_and_grad(z, y)
+    eng.backward(gz)
+    assert eng.store.grad.abs().max().item() > 0 and not eng._grad_is_zero
+    step(x, y)
+    torch.cuda.synchronize()
+    p2 = eng.store.flat.clone()
+    d1, d2 = p1 - p0, p2 - p1
+    assert d1.norm().item() > 0
+    clean, stale = ((d2 - d1).norm() / d1.norm()).item(), ((d2 - 2 * d1).norm() / d1.norm()).item()
+    print(f"second replay's update d2 vs the first's d1: |d2 - d1| / |d1| = {clean:.3f}, |d2 - 2 d1| / |d1| = {stale:.3f} "
+          f"(two evaluations of one bf16 gradient differ by ~0.2-0.5 themselves: atomics order, ReLU masks)")
+    assert clean < 0.7 * stale, (clean, stale)        # d2 is one gradient step, not two
+    assert eng._grad_is_zero and eng.store.grad.abs().max().item() == 0
+
+
 def test_hipgraph_captures_the_wrn_step_with_cu_sharing_and_lagged_events():
     """The WideResNet step inside a hipGraph: the second stream is forked into the capture, the per-unit events that
     order it against the main stream (one-unit lag) are captured as graph dependencies, the CU-sharing schedule is
@@ -716,3 +749,43 @@ def test_resnet_two_stream_backward_equals_the_serial_one_bit_for_bit(determinis
         assert torch.equal(z1, z2) and l1 == l2 == l2b
         assert torch.equal(g2, g2b), f"two runs differ, rel-L2 {_rel_l2(g2b, g2):.3e}"
         assert torch.equal(g1, g2), f"two streams + shared buffers vs one stream + private buffers: rel-L2 {_rel_l2(g2, g1):.3e}"
+
+
+def test_resnet_bn1_sums_from_the_data_gradient_epilogue_equal_the_pass_of_their_own(deterministic_mode):
+    """ResNetEngine.fuse_bn1_bwd: conv2's data gradient emits bn1's backward sums from its fp32 accumulators
+    (nbdt_conv_igemm_bnbwd + nbdt_bn_bwd_fused) instead of a reduction pass over the bf16 gradient it stored
+    (nbdt_bn_bwd).  Same step, both ways, at 32x32 and at config 4's 64x64: identical logits and loss, every parameter
+    gradient equal to bf16-rounding level (the sums see the gradient before / after its rounding to bf16)."""
+    for size, classes, ds in ((64, 200, "TinyImagenet200"), (32, 10, "CIFAR10")):
+        crit = SoftTreeSupLoss(dataset=ds, criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18")
+        g = torch.Generator().manual_seed(23)
+        x = torch.randn(32, 3, size, size, generator=g).to(DEV)
+        y = torch.randint(0, classes, (32,), generator=g).to(DEV)
+        fused = E.ResNetEngine(num_classes=classes, device=DEV, seed=11)
+        plain = E.ResNetEngine(num_classes=classes, device=DEV, seed=11)
+        assert fused.fuse_bn1_bwd
+        plain.fuse_bn1_bwd = False
+        calls = {"bnbwd": 0}
+        real = ops.conv_igemm_bnbwd
+
+        def spy(*a, **k):
+            calls["bnbwd"] += 1
+            return real(*a, **k)
+
+        ops.conv_igemm_bnbwd = spy
+        try:
+            zf, lf, gf = _one_backward(fused, crit, x, y)
+            n_fused = calls["bnbwd"]
+            zp, lp, gp = _one_backward(plain, crit, x, y)
+        finally:
+            ops.conv_igemm_bnbwd = real
+        assert n_fused == len(fused.blocks) and calls["bnbwd"] == n_fused      # one per basic block / none
+        assert torch.equal(zf, zp) and lf == lp
+        gb = plain.named_params("grad")
+        errs = sorted((_rel_l2(a, gb[name]), name) for name, a in fused.named_params("grad").items())
+        worst, median = errs[-1], errs[len(errs) // 2][0]
+        print(f"{ds}: parameter-gradient rel-L2 between the two forms: worst {worst[0]:.2e} ({worst[1]}), median "
+              f"{median:.2e}; whole flat gradient {_rel_l2(gf, gp):.2e}")
+        # (measured 1e-2 / 3e-3: 1-ulp differences of the bf16 gradients downstream of slightly different sums; a wrong
+        # sum shows as >= 1e-1 in the BatchNorm's own dgamma / dbeta)
+        assert worst[0] < 4e-2 and median < 1e-2 and _rel_l2(gf, gp) < 1e-2, errs[-3:]

@@ -304,60 +304,93 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
 // Wide heads (EfficientNet: 1280 -> 1000) : LDS-tiled fp32 GEMM, 64x64 outputs per block, 4x4 per thread.
 //   C[i][j] (+)= sum_l A(i,l) * B(l,j) [+ bias[j]];   A(i,l) = A[i*ai + l*al],  B(l,j) = B[l*bl + j*bj]
 // (the one-wave-per-output kernels above took 105 / 204 / 133 us for fwd / dgrad / wgrad at B=128)
-template <bool ACC>
+// At batch 128 the forward / data-gradient grids are 32 / 40 blocks, one wave per SIMD: the K loop's global loads
+// are what such a block waits for.  Steps of 32 with the NEXT step's 16 elements per thread already in registers
+// while this step's products are formed (round 4: 186 -> see profiles/r04_head_ab.txt); every output is still one
+// chain of multiply-adds in ascending l, so the results are the bits the 16-step kernel gave.
+// T: tile edge (64: 4x4 outputs per thread; 32: 2x2 -- four times the blocks when a 64-tile grid would leave most CUs
+// idle), BK: K elements per step.
+template <bool ACC, int T, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long long ai, long long al,
                                                        const float* __restrict__ Bm, long long bl, long long bj,
                                                        const float* __restrict__ bias, float* __restrict__ C,
                                                        int ldc, int M, int N, int L) {
-  __shared__ float As[16][68];
-  __shared__ float Bs[16][68];
+  constexpr int Q = BK * T / 256;                  // elements per thread per operand tile
+  constexpr int R = T / 16;                        // thread owns R x R outputs: rows ti*R.., cols tj*R..
+  __shared__ float As[BK][T + 4];
+  __shared__ float Bs[BK][T + 4];
   const int tid = threadIdx.x;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  const int ti = tid >> 4, tj = tid & 15;          // thread owns rows ti*4..+3, cols tj*4..+3
-  float acc[4][4];
+  const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
+  const int ti = tid >> 4, tj = tid & 15;
+  float acc[R][R];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < R; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-  for (int l0 = 0; l0 < L; l0 += 16) {
+    for (int b = 0; b < R; ++b) acc[a][b] = 0.f;
+  float ra[Q], rb[Q];
+  // element e of a tile <-> (row / col, l): consecutive threads walk the operand's unit-stride dimension
+  auto a_pos = [&](int e, int& ia, int& la) { if (al == 1) { la = e & (BK - 1); ia = e / BK; } else { ia = e & (T - 1); la = e / T; } };
+  auto b_pos = [&](int e, int& jb, int& lb) { if (bj == 1) { jb = e & (T - 1); lb = e / T; } else { lb = e & (BK - 1); jb = e / BK; } };
+  auto fetch = [&](int l0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + 256 * q;                 // 1024 elements per operand tile
-      // walk the unit-stride dimension with consecutive threads
-      int ia, la, lb, jb;
-      if (al == 1) { la = e & 15; ia = e >> 4; } else { ia = e & 63; la = e >> 6; }
-      if (bj == 1) { jb = e & 63; lb = e >> 6; } else { lb = e & 15; jb = e >> 4; }
-      const int gi = i0 + ia, gl = l0 + la;
-      As[la][ia] = (gi < M && gl < L) ? A[gi * ai + gl * al] : 0.f;
-      const int gj = j0 + jb, gl2 = l0 + lb;
-      Bs[lb][jb] = (gj < N && gl2 < L) ? Bm[gl2 * bl + gj * bj] : 0.f;
+    for (int q = 0; q < Q; ++q) {
+      int ia, la, jb, lb;
+      a_pos(tid + 256 * q, ia, la);
+      b_pos(tid + 256 * q, jb, lb);
+      const int gi = i0 + ia, gl = l0 + la, gj = j0 + jb, gl2 = l0 + lb;
+      ra[q] = (gi < M && gl < L) ? A[gi * ai + gl * al] : 0.f;
+      rb[q] = (gj < N && gl2 < L) ? Bm[gl2 * bl + gj * bj] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int l0 = 0; l0 < L; l0 += BK) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      int ia, la, jb, lb;
+      a_pos(tid + 256 * q, ia, la);
+      b_pos(tid + 256 * q, jb, lb);
+      As[la][ia] = ra[q];
+      Bs[lb][jb] = rb[q];
     }
     __syncthreads();
+    if (l0 + BK < L) fetch(l0 + BK);
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
-      const float4 av = *(const float4*)&As[l][ti * 4];
-      const float4 bv = *(const float4*)&Bs[l][tj * 4];
-      const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+    for (int l = 0; l < BK; ++l) {
+      float a4[R], b4[R];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < R; ++a) { a4[a] = As[l][ti * R + a]; b4[a] = Bs[l][tj * R + a]; }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += a4[a] * b4[b];
+      for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b) acc[a][b] += a4[a] * b4[b];
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int gi = i0 + ti * 4 + a;
+  for (int a = 0; a < R; ++a) {
+    const int gi = i0 + ti * R + a;
     if (gi >= M) continue;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int gj = j0 + tj * 4 + b;
+    for (int b = 0; b < R; ++b) {
+      const int gj = j0 + tj * R + b;
       if (gj >= N) continue;
       float v = acc[a][b] + (bias ? bias[gj] : 0.f);
       float* dst = C + (size_t)gi * ldc + gj;
       *dst = ACC ? *dst + v : v;
     }
   }
+}
+
+// C[M, N] (+)= A B over L: 64-edge tiles when they give the chip at least 128 blocks, else 32-edge ones
+template <bool ACC>
+static void launch_gemm_f32(hipStream_t st, const float* A, long long ai, long long al, const float* Bm, long long bl,
+                            long long bj, const float* bias, float* C, int ldc, int M, int N, int L) {
+  if ((long long)((M + 63) / 64) * ((N + 63) / 64) >= 128)
+    hipLaunchKernelGGL((gemm_f32_kernel<ACC, 64, 32>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, ai, al,
+                       Bm, bl, bj, bias, C, ldc, M, N, L);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<ACC, 32, 64>), dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, A, ai, al,
+                       Bm, bl, bj, bias, C, ldc, M, N, L);
 }
 
 __global__ __launch_bounds__(256) void colsum_acc_kernel(const float* __restrict__ g, int B, int N,
@@ -373,8 +406,7 @@ extern "C" int nbdt_linear_fwd(const float* x, const float* w, const float* b, i
                                float* z, void* stream) {
   NBDT_REQUIRE(x && w && z && B > 0 && K > 0 && N > 0, "bad linear arguments");
   if (N >= 64) {
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((N + 63) / 64, (B + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       x, (long long)K, 1ll, w, 1ll, (long long)K, b, z, N, B, N, K);
+    launch_gemm_f32<false>((hipStream_t)stream, x, (long long)K, 1ll, w, 1ll, (long long)K, b, z, N, B, N, K);
     NBDT_LAUNCH_CHECK();
     return NBDT_OK;
   }
@@ -391,13 +423,11 @@ extern "C" int nbdt_linear_bwd(const float* x, const float* w, const float* gz, 
   hipStream_t st = (hipStream_t)stream;
   if (N >= 64) {
     if (gx) {   // gx[B,K] = gz[B,N] w[N,K]
-      hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3((K + 63) / 64, (B + 63) / 64), dim3(256), 0, st, gz,
-                         (long long)N, 1ll, w, (long long)K, 1ll, (const float*)nullptr, gx, K, B, K, N);
+      launch_gemm_f32<false>(st, gz, (long long)N, 1ll, w, (long long)K, 1ll, (const float*)nullptr, gx, K, B, K, N);
       NBDT_LAUNCH_CHECK();
     }
     if (gw) {   // gw[N,K] += gz^T[N,B] x[B,K]
-      hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, st, gz, 1ll,
-                         (long long)N, x, (long long)K, 1ll, (const float*)nullptr, gw, K, N, K, B);
+      launch_gemm_f32<true>(st, gz, 1ll, (long long)N, x, (long long)K, 1ll, (const float*)nullptr, gw, K, N, K, B);
       NBDT_LAUNCH_CHECK();
       if (gb) {
         hipLaunchKernelGGL(colsum_acc_kernel, dim3((N + 255) / 256), dim3(256), 0, st, gz, B, N, gb);

@@ -505,60 +505,79 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __r
 // thread = (8-channel chunk, output row ho), blockIdx.z = kernel row r.  The thread walks its row left to
 // right keeping the K input pixels under the current output in registers (a sliding window: S new
 // 16-byte loads per output pixel instead of K), K x 8 fp32 accumulators.
-template <int K, int S>
+// A block is CB channel chunks (at most 32: one 512-byte run per pixel) x PY output rows; blockIdx.x = (row block,
+// channel block).  Wide layers used to put ALL their channel chunks into a block -- 1152 channels: 144 threads, ONE
+// row -- so a block folded one row of 18 images before its K*8 atomics per thread, and the chip held 630 waves, each a
+// serial walk over 126 pixels.  With the channels split, 7 rows fold in the block and the batch chunk shrinks instead.
+template <int K, int S, int U>
 __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* __restrict__ x,
                                                                  const bf16_t* __restrict__ gy, DwGeom d, int PY,
-                                                                 int bchunk, float* __restrict__ dw,
-                                                                 long long row_stride) {
+                                                                 int CB, int cblocks, int bchunk,
+                                                                 float* __restrict__ dw, long long row_stride) {
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
-  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, r = blockIdx.z;
+  const int cb = blockIdx.x % cblocks, rb = blockIdx.x / cblocks;
+  const int cxl = threadIdx.x % CB, py = threadIdx.x / CB, r = blockIdx.z;
+  const int cx = cb * CB + cxl;
+  const bool live = cx < g.c8;
   constexpr int PAD = K / 2;
   float acc[K][8];
 #pragma unroll
   for (int s = 0; s < K; ++s)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[s][i] = 0.f;
-  const int ho = blockIdx.x * PY + py;
+  const int ho = rb * PY + py;
   const int hi = ho * S + r - PAD;
   const int b0 = blockIdx.y * bchunk;
   const int b1 = b0 + bchunk < g.B ? b0 + bchunk : g.B;
-  if (ho < g.H && hi >= 0 && hi < d.Hi) {
+  if (live && ho < g.H && hi >= 0 && hi < d.Hi) {
     for (int b = b0; b < b1; ++b) {    // images of this block's batch chunk: one fold + atomics for all
       const bf16_t* xrow = x + (size_t)b * d.imgi + (hi + 1) * d.rowi + g.C + cx * 8;   // + wi * C
       const bf16_t* grow = gy + (size_t)b * g.img + (ho + 1) * g.row + g.C + cx * 8;    // + wo * C
       float win[K][8];
-      auto fetch = [&](float* dst, int wi) {
-        if (wi >= -1 && wi <= d.Wi) {      // inside the padded row (the border itself is zero)
-          unpack8(*(const u32x4_t*)(xrow + wi * g.C), dst);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) dst[i] = 0.f;
-        }
+      const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+      auto raw = [&](int wi) -> u32x4_t {      // inside the padded row (the border itself is zero), else zero
+        return (wi >= -1 && wi <= d.Wi) ? *(const u32x4_t*)(xrow + wi * g.C) : zero4;
       };
 #pragma unroll
-      for (int j = 0; j < K; ++j) fetch(win[j], j - PAD);
-      for (int wo = 0; wo < g.W; ++wo) {
-        float fg[8];
-        unpack8(*(const u32x4_t*)(grow + wo * g.C), fg);
+      for (int j = 0; j < K; ++j) unpack8(raw(j - PAD), win[j]);
+      // U output pixels per trip: their gradient vectors and the S new window columns each of them brings are all
+      // requested before the first is used (U * (1 + S) 16-byte loads in flight per thread; one at a time, the walk
+      // was a chain of load round trips -- 124 us for the 2 x 48 MB of a 28x28x240 layer, profiles/r04_dw_wgrad.txt)
+      for (int wo0 = 0; wo0 < g.W; wo0 += U) {
+        u32x4_t rg[U], rx[U][S];
 #pragma unroll
-        for (int j = 0; j < K; ++j)
+        for (int u = 0; u < U; ++u) {
+          const int wo = wo0 + u;
+          rg[u] = wo < g.W ? *(const u32x4_t*)(grow + wo * g.C) : zero4;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[j][i] += fg[i] * win[j][i];
+          for (int j = 0; j < S; ++j) rx[u][j] = wo + 1 < g.W ? raw((wo + 1) * S - PAD + (K - S) + j) : zero4;
+        }
 #pragma unroll
-        for (int j = 0; j + S < K; ++j)
+        for (int u = 0; u < U; ++u) {
+          if (wo0 + u < g.W) {
+            float fg[8];
+            unpack8(rg[u], fg);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) win[j][i] = win[j + S][i];
-        if (wo + 1 < g.W) {
+            for (int j = 0; j < K; ++j)
 #pragma unroll
-          for (int j = K - S; j < K; ++j) fetch(win[j], (wo + 1) * S - PAD + j);
+              for (int i = 0; i < 8; ++i) acc[j][i] += fg[i] * win[j][i];
+#pragma unroll
+            for (int j = 0; j + S < K; ++j)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) win[j][i] = win[j + S][i];
+#pragma unroll
+            for (int j = 0; j < S; ++j) unpack8(rx[u][j], win[K - S + j]);
+          }
         }
       }
     }
   }
   // row_stride: 0, or (deterministic mode) K*K*C: a zeroed copy of dw per (row block, batch chunk), folded in order
   float* dst = dw + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * row_stride + (size_t)r * K * g.C;
-  block_fold<K>(acc, cx, py, g.c8, PY, lds, [&](int s, int c, float v) { atomicAdd(dst + (size_t)s * g.C + c, v); });
+  block_fold<K>(acc, cxl, py, CB, PY, lds, [&](int s, int c, float v) {
+    if (live) atomicAdd(dst + (size_t)s * g.C + cb * CB * 8 + c, v);
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -912,15 +931,22 @@ extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, 
   if (rc) return rc;
   const DwGeom d = dw_geom(B, H, W, C, k, stride, 1);
   const int Ho = H / stride;
-  int PY = kThreads / d.out.c8;
-  if (PY < 1) PY = 1;
+  const int cblocks = (d.out.c8 + 31) / 32, CB = (d.out.c8 + cblocks - 1) / cblocks;
+  int PY = kThreads / CB;
   if (PY > Ho) PY = Ho;
-  const int threads = d.out.c8 * PY;
-  // every block ends in c8*k*8 global atomics: let a block walk several images when rows are short
-  int bchunk = 128 / (W / stride);
+  const int threads = CB * PY;
+  // every block ends in CB*k*8 global atomics on addresses every other block of its channels adds to as well: let a
+  // thread walk about NBDT_DW_TARGET output pixels (several images when rows are short) before the block folds
+  // (profiles/r04_dw_wgrad.txt: rows of 28+ outputs are fastest at ~128 pixels per thread, shorter ones at ~64)
+#ifdef NBDT_DW_TARGET            // timing-only builds: one target everywhere
+  const int target_px = NBDT_DW_TARGET;
+#else
+  const int target_px = W / stride >= 28 ? 128 : 64;
+#endif
+  int bchunk = target_px / (W / stride);
   if (bchunk < 1) bchunk = 1;
   if (bchunk > B) bchunk = B;
-  const dim3 grid((Ho + PY - 1) / PY, (B + bchunk - 1) / bchunk, k), blk(threads);
+  const dim3 grid(((Ho + PY - 1) / PY) * cblocks, (B + bchunk - 1) / bchunk, k), blk(threads);
   const size_t shmem = (size_t)threads * k * 8 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   float* target = dw;
@@ -933,9 +959,21 @@ extern "C" int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, 
     NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)nrows * n_dw * sizeof(float), st));
     row_stride = (long long)n_dw;
   }
-#define NBDT_GO(K, S) hipLaunchKernelGGL((dw_bwd_weight_kernel<K, S>), grid, blk, shmem, st, (const bf16_t*)x, (const bf16_t*)gy, d, PY, bchunk, target, row_stride)
-  if (k == 3) { if (stride == 1) NBDT_GO(3, 1); else NBDT_GO(3, 2); }
-  else { if (stride == 1) NBDT_GO(5, 1); else NBDT_GO(5, 2); }
+#define NBDT_GO(K, S, U) hipLaunchKernelGGL((dw_bwd_weight_kernel<K, S, U>), grid, blk, shmem, st, (const bf16_t*)x, (const bf16_t*)gy, d, PY, CB, cblocks, bchunk, target, row_stride)
+#ifdef NBDT_DW_U          // timing-only builds: one U everywhere
+#define NBDT_GO_S1(K) { NBDT_GO(K, 1, NBDT_DW_U); }
+#define NBDT_GO_S2(K) { NBDT_GO(K, 2, NBDT_DW_U); }
+#else
+  // pixels in flight per thread: the short-row layers (<= 28 wide: few waves per CU, a row is a chain of round trips)
+  // want 8; the long-row stride-1 layers are bandwidth-bound and lose occupancy to the registers of more than 1
+  const bool long_rows = W / stride >= 56;
+#define NBDT_GO_S1(K) { if (long_rows) NBDT_GO(K, 1, 1); else NBDT_GO(K, 1, 8); }
+#define NBDT_GO_S2(K) { NBDT_GO(K, 2, 4); }
+#endif
+  if (k == 3) { if (stride == 1) NBDT_GO_S1(3) else NBDT_GO_S2(3) }
+  else { if (stride == 1) NBDT_GO_S1(5) else NBDT_GO_S2(5) }
+#undef NBDT_GO_S1
+#undef NBDT_GO_S2
 #undef NBDT_GO
   NBDT_LAUNCH_CHECK();
   if (target != dw) return det_fold(st, target, nrows, n_dw, dw);

@@ -88,8 +88,12 @@ __device__ __forceinline__ void load_bn(BnRegs& r, const float* mean, const floa
   }
 }
 
-// fold NQ*8 per-thread partials over the PY pixel rows of the block; element e of chunk cx ends up in
-// thread (cx, e % PY) which hands it to `sink(q, channel, value)`
+// fold NQ*8 per-thread partials over the PY pixel rows of the block and hand every sum to `sink(q, channel, value)`.
+// Output o = q * (c8*8) + channel goes to thread o % (c8*PY): CONSECUTIVE THREADS HOLD CONSECUTIVE CHANNELS, so the
+// sinks' global atomics are one contiguous 256-byte run per wave.  (Round 1 gave chunk cx's element e to thread
+// (cx, e % PY): lanes 32 bytes apart, 64 sectors per atomic instruction -- that, not the arithmetic, was most of the
+// time of every statistics / weight-gradient kernel of this file on the narrow late layers: profiles/r04_dw_wgrad.txt.)
+// A sum is still its PY partials in ascending row order: the same bits as before.
 template <int NQ, typename Sink>
 __device__ __forceinline__ void block_fold(float (&acc)[NQ][8], int cx, int py, int c8, int PY, float* lds,
                                            Sink sink) {
@@ -99,10 +103,13 @@ __device__ __forceinline__ void block_fold(float (&acc)[NQ][8], int cx, int py, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) mine[q * 8 + i] = acc[q][i];
   __syncthreads();
-  for (int e = py; e < NQ * 8; e += PY) {
+  const int nch = c8 * 8, nthr = c8 * PY;
+  for (int o = py * c8 + cx; o < NQ * nch; o += nthr) {
+    const int q = o / nch, c = o - q * nch;
+    const float* src = lds + (size_t)(c >> 3) * (NQ * 8) + q * 8 + (c & 7);
     float s = 0.f;
-    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + cx) * (NQ * 8) + e];
-    sink(e >> 3, cx * 8 + (e & 7), s);
+    for (int r = 0; r < PY; ++r) s += src[(size_t)r * c8 * (NQ * 8)];
+    sink(q, c, s);
   }
 }
 
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* _
   // row_stride: 0, or (deterministic mode) K*K*C: a zeroed copy of dw per (row block, batch chunk), folded in order
   float* dst = dw + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * row_stride + (size_t)r * K * g.C;
   block_fold<K>(acc, cxl, py, CB, PY, lds, [&](int s, int c, float v) {
-    if (live) atomicAdd(dst + (size_t)s * g.C + cb * CB * 8 + c, v);
+    if (cb * CB * 8 + c < g.C) atomicAdd(dst + (size_t)s * g.C + cb * CB * 8 + c, v);   // (the last channel block may be short)
   });
 }
 

@@ -50,12 +50,16 @@ __device__ __forceinline__ void block_fold_to_slots(float (&acc)[NQ][8], int cx,
 #pragma unroll
     for (int i = 0; i < 8; ++i) mine[q * 8 + i] = acc[q][i];
   __syncthreads();
-  // thread (cx, py) folds element e = py, py+PY, ... of its channel chunk
-  for (int e = py; e < NQ * 8; e += PY) {
+  // output o = q * (c8*8) + channel goes to thread o % (c8*PY): consecutive threads add to consecutive addresses (one
+  // 256-byte run per wave; thread (cx, py) folding element e = py, py+PY, ... of ITS chunk put a wave's lanes 32 bytes
+  // apart -- 64 sectors per atomic instruction once c8 >= 64).  Each sum is its PY partials in ascending row order.
+  const int nch = c8 * 8, nthr = c8 * PY;
+  for (int o = py * c8 + cx; o < NQ * nch; o += nthr) {
+    const int q = o / nch, c = o - q * nch;
+    const float* src = lds + (size_t)(c >> 3) * (NQ * 8) + q * 8 + (c & 7);
     float s = 0.f;
-    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + cx) * (NQ * 8) + e];
-    const int q = e >> 3, i = e & 7;
-    atomicAdd(scratch + ((size_t)(blockIdx.x & slot_mask) * NQ + q) * C + cx * 8 + i, s);
+    for (int r = 0; r < PY; ++r) s += src[(size_t)r * c8 * (NQ * 8)];
+    atomicAdd(scratch + ((size_t)(blockIdx.x & slot_mask) * NQ + q) * C + c, s);
   }
 }
 
@@ -477,11 +481,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* _
     for (int i = 0; i < 8; ++i) { mine[i] = acc[0][i]; mine[8 + i] = acc[1][i]; }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < c8 * 16; e += 1024) {
-    const int ccx = e >> 4, k = e & 15;
+  for (int e = threadIdx.x; e < c8 * 16; e += 1024) {     // e = which * (c8*8) + channel: contiguous adds per wave
+    const int which = e / (c8 * 8), c = e - which * (c8 * 8);
     float s = 0.f;
-    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + ccx) * 16 + k];
-    atomicAdd(scratch + ((size_t)(blockIdx.x & slot_mask) * 2 + (k >> 3)) * g.C + ccx * 8 + (k & 7), s);
+    for (int r = 0; r < PY; ++r) s += lds[((size_t)r * c8 + (c >> 3)) * 16 + which * 8 + (c & 7)];
+    atomicAdd(scratch + ((size_t)(blockIdx.x & slot_mask) * 2 + which) * g.C + c, s);
   }
 }
 

@@ -94,6 +94,40 @@ def test_depthwise_conv_forward_and_gradients(k, stride, C, H, W):
     assert ((rstd.cpu() - want_rstd).abs() / want_rstd).max().item() < 2e-3
 
 
+@pytest.mark.parametrize("B,k,stride,C,H,W", [(11, 5, 1, 1152, 7, 7),     # 5 channel blocks of 29 chunks (the last short), batch chunks 9 + 2
+                                               (5, 3, 1, 96, 56, 56),       # long rows: one pixel in flight, batch chunks 2 + 2 + 1
+                                               (5, 3, 2, 144, 56, 56),      # stride 2, 28 outputs per row: 4 + 1
+                                               (7, 5, 1, 672, 14, 14),      # 3 channel blocks of 28, rows of 14 in two trips of 8
+                                               (4, 3, 1, 40, 9, 13)])       # odd sizes, 5 chunks, one block
+def test_depthwise_weight_gradient_over_channel_blocks_and_batch_chunks(B, k, stride, C, H, W):
+    """nbdt_dwconv_bwd_weight at the launch shapes EfficientNet-B0's layers produce (channel blocks in blockIdx.x, several
+    images per block, 8 / 4 / 1 output pixels' loads in flight): against torch autograd in fp32 on the same bf16 operands,
+    in the default and the deterministic (row per block + ordered fold) mode, twice (the second call accumulates)."""
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = _bf(torch.randn(B, C, H, W, generator=g))
+    gy = _bf(torch.randn(B, C, H // stride, W // stride, generator=g))
+    wr = torch.zeros(C, 1, k, k, requires_grad=True)
+    F.conv2d(x, wr, None, stride, k // 2, 1, C)[:, :, :H // stride, :W // stride].backward(gy)
+    want = wr.grad.view(C, k * k).t()
+    xp, gyp = _padded_from(x), _padded_from(gy)
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            dw = torch.zeros(k * k, C, device=DEV)
+            ops.dwconv_bwd_weight(xp, gyp, dw, k, stride)
+            one = dw.clone()
+            ops.dwconv_bwd_weight(xp, gyp, dw, k, stride)
+            if det:
+                again = torch.zeros(k * k, C, device=DEV)
+                ops.dwconv_bwd_weight(xp, gyp, again, k, stride)
+                assert torch.equal(again, one)                      # bit-reproducible
+        finally:
+            ops.set_deterministic(False)
+        scale = want.abs().max().item()
+        assert (one.cpu() - want).abs().max().item() <= 1e-4 * scale, (det, (one.cpu() - want).abs().max().item(), scale)
+        assert (dw.cpu() - 2 * want).abs().max().item() <= 2e-4 * scale
+
+
 @pytest.mark.parametrize("C,H,W,act", [(32, 8, 8, ops.ACT_SWISH), (96, 5, 7, ops.ACT_SWISH), (160, 4, 4, ops.ACT_NONE),
                                        (1280, 2, 2, ops.ACT_SWISH), (64, 6, 6, ops.ACT_RELU)])
 def test_bn_act_apply_pool_and_backward_forms(C, H, W, act):

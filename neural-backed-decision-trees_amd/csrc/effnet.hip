@@ -616,6 +616,8 @@ __global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float* __restri
     }
   }
   __syncthreads();
+  // (a thread per row of W2 [Cr][S] walking s: the row is 4 S contiguous bytes that stay in L1 across the walk -- a wave
+  // per row with lanes along s measured 2-4x slower, profiles/r04_dw_wgrad.txt)
   for (int c = threadIdx.x; c < C; c += nthr) {
     float v = 0.f;
     if (c < Cr) {
@@ -635,9 +637,10 @@ __global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restri
                                                           const float* __restrict__ w2, int C, int Cr, int S,
                                                           float* __restrict__ dpre2, float* __restrict__ dpre1,
                                                           float* __restrict__ gpool) {
-  extern __shared__ float lds[];   // d2[Cr] | d1[S]
+  extern __shared__ float lds[];   // d2[Cr] | d1[S] | per-wave partials [nwave][S]
   float* d2 = lds;
   float* d1 = lds + Cr;
+  float* part = d1 + S;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nthr = blockDim.x, nwave = blockDim.x >> 6;
   for (int c = threadIdx.x; c < Cr; c += nthr) {
@@ -647,18 +650,35 @@ __global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restri
     dpre2[(size_t)b * Cr + c] = v;
   }
   __syncthreads();
-  for (int s = wave; s < S; s += nwave) {
-    float acc = 0.f;
-    for (int c = lane; c < Cr; c += 64) acc += w2[(size_t)c * S + s] * d2[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) {
-      const float p = pre1[(size_t)b * S + s];
-      const float sg = sigmoidf_(p);
-      const float v = acc * sg * (1.f + p * (1.f - sg));
-      d1[s] = v;
-      dpre1[(size_t)b * S + s] = v;
+  // sum_c W2[c][s] d2[c].  Wide layers (16 waves): a wave walks rows c = wave, wave + 16, ... with its lanes along s
+  // (contiguous reads of a row) and the waves' partial vectors are added in wave order -- 60 -> 44 us at 1152 x 48, where
+  // lanes along c read W2 with stride S, 64 lines per load, 18 times per s.  Narrow layers keep the wave-per-s form (it
+  // measures the same or better there).
+  if (nwave > 4) {
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s2 = s0 + lane;
+      float acc = 0.f;
+      if (s2 < S)
+        for (int c = wave; c < Cr; c += nwave) acc += w2[(size_t)c * S + s2] * d2[c];
+      if (s2 < S) part[wave * S + s2] = acc;
     }
+    __syncthreads();
+  }
+  for (int s = nwave > 4 ? threadIdx.x : wave; s < S; s += nwave > 4 ? nthr : nwave) {
+    float acc = 0.f;
+    if (nwave > 4) {
+      for (int wv = 0; wv < nwave; ++wv) acc += part[wv * S + s];
+    } else {
+      for (int c = lane; c < Cr; c += 64) acc += w2[(size_t)c * S + s] * d2[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (lane != 0) continue;
+    }
+    const float p = pre1[(size_t)b * S + s];
+    const float sg = sigmoidf_(p);
+    const float v = acc * sg * (1.f + p * (1.f - sg));
+    d1[s] = v;
+    dpre1[(size_t)b * S + s] = v;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += nthr) {
@@ -680,14 +700,18 @@ __global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restr
                                                             float* __restrict__ db2) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Cr * S) return;
+  // the thread owns TWO outputs, each where its neighbours' are contiguous: dw1[s][c] with consecutive threads along c,
+  // dw2[c2][s2] (= dw2 + idx) with consecutive threads along s -- one (c, s) pair for both put the dw2 atomics S floats
+  // apart, 64 sectors per instruction
   const int c = idx % Cr, s = idx / Cr;
+  const int s2 = idx % S, c2 = idx / S;
   const int b0 = blockIdx.y * bchunk;
   const int b1 = b0 + bchunk < B ? b0 + bchunk : B;
   float a1 = 0.f, a2 = 0.f, sb1 = 0.f, sb2 = 0.f;
 #pragma unroll 4
   for (int b = b0; b < b1; ++b) {
-    const float p = pre1[(size_t)b * S + s];
-    const float e1 = dpre1[(size_t)b * S + s], e2 = dpre2[(size_t)b * Cr + c];
+    const float p = pre1[(size_t)b * S + s2];
+    const float e1 = dpre1[(size_t)b * S + s], e2 = dpre2[(size_t)b * Cr + c2];
     const float pl = pooled[(size_t)b * C + c];
     const float h = p * sigmoidf_(p);
     a1 += e1 * pl;
@@ -695,10 +719,10 @@ __global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restr
     sb1 += e1;
     sb2 += e2;
   }
-  atomicAdd(dw1 + (size_t)s * Cr + c, a1);
-  atomicAdd(dw2 + (size_t)c * S + s, a2);
+  atomicAdd(dw1 + idx, a1);                     // = dw1 + s * Cr + c
+  atomicAdd(dw2 + idx, a2);                     // = dw2 + c2 * S + s2
   if (c == 0) atomicAdd(db1 + s, sb1);
-  if (s == 0) atomicAdd(db2 + c, sb2);
+  if (s2 == 0) atomicAdd(db2 + c2, sb2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1008,7 +1032,7 @@ extern "C" int nbdt_se_gate_bwd(const float* dgate, const float* gate, const flo
   NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(C_real > 256 ? 1024 : 256),
-                     (size_t)(C_real + S) * sizeof(float), st, dgate, gate, pre1, w1, w2, C, C_real, S, dpre2, dpre1,
+                     (size_t)(C_real + S + (C_real > 256 ? 16 : 4) * S) * sizeof(float), st, dgate, gate, pre1, w1, w2, C, C_real, S, dpre2, dpre1,
                      gpool);
   NBDT_LAUNCH_CHECK();
   const int n = C_real * S;

@@ -758,7 +758,12 @@ static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, HaloGeom* 
 // at least 3/4 of the 256 CUs a block (every WRN-28-10 layer at 512 images per GPU), else the 256-pixel kernel.
 // desc.wide_tile: 0/1 automatic, 2 force the 512-pixel kernel, 3 force the 256-pixel one (tests, A/B).
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
-  if (d->ntaps != 9 || d->in_base != 0 || d->accumulate) return false;
+#ifdef NBDT_HALO_NO_ACCUMULATE          // A/B builds: accumulating data gradients on the first-generation kernel (rounds 1-3)
+  if (d->accumulate) return false;
+#endif
+  // (an accumulating launch passes its own output as the residual: every element is read and written by the one thread
+  // that owns it, so in place is safe)
+  if (d->ntaps != 9 || d->in_base != 0) return false;
   if (d->in_ws != d->cin || d->in_hs != (d->gw + 2) * d->cin || d->in_bs != (d->gh + 2) * d->in_hs) return false;
   for (int t = 0; t < 9; ++t)
     if (d->tap_off[t] != (t / 3) * d->in_hs + (t % 3) * d->in_ws) return false;

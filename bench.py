@@ -355,6 +355,12 @@ def main():
 
     dt_nocomm = None
     if world > 1:
+        # replicas must still be bit-identical here: same initial weights, every rank applied the SAME all-reduced
+        # gradient in every step so far (timed loop and roofline passes alike); two checksums per rank, gathered
+        flat = eng.store.flat.double()
+        sums = [None] * world
+        torch.distributed.all_gather_object(sums, (float(flat.sum().item()), float((flat * flat).sum().item())))
+        del flat
         # what the gradient exchange costs a step: the same loop without it (ranks drift apart, nothing after
         # this point reads the weights except the per-rank roofline pass above, which already ran)
         nc_steps = min(args.steps, 5)
@@ -390,6 +396,7 @@ def main():
     if world > 1:
         out["comm"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                        "cu_share_per_rank": shares,
+                       "replica_checksums": sums, "replicas_identical": all(c == sums[0] for c in sums),
                        "allreduce_bytes_per_rank": int(eng.store.grad.numel()) * 4, "buckets": 3,
                        "ms_per_step_without_allreduce": round(1e3 * dt_nocomm, 3),
                        "allreduce_ms_exposed": round(ms - 1e3 * dt_nocomm, 3)}

@@ -436,6 +436,10 @@ int nbdt_ref_stem_wgrad(const float* img, const float* gy, int32_t B, int32_t H,
  * w: fp32 [cout_real][3][3][3] (co, r, s, ci). */
 int nbdt_stem_conv(const float* img, const float* w, int32_t B, int32_t H, int32_t W,
                    int32_t cout_real, int32_t cpad, int32_t stride, void* out, void* stream);
+/* Weight gradient of that conv: dw[cout_real][3][3][3] (fp32) += sum over pixels of gy (padded NHWC bf16, channels
+ * [0, cout_real)) x img.  cout_real must be a multiple of 8 and <= 72 (<= cpad): the kernel (round 4) reads the gradient
+ * tile from LDS as float4 and keeps at most two 4-output groups per thread (every stem of the supported backbones is 16,
+ * 32 or 64 wide).  Anything else returns NBDT_EINVAL -- rounds 1-3 accepted any cout_real <= 75. */
 int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int32_t H, int32_t W,
                     int32_t cout_real, int32_t cpad, int32_t stride, float* dw, void* stream);
 /* nn.Linear: z[B][N] = x[B][K] w[N][K]^T + b (fp32) and its backward */

@@ -11,6 +11,25 @@
 
 #include "../../include/nbdt_hip.h"
 
+// ---- timing-experiment switches.  A handful of -D switches in the kernel sources skip, fake or re-time part of a kernel
+// (ablations, "what would X buy" experiments, s_memtime stamps): several of them produce WRONG results by design.  They
+// compile only together with -DNBDT_TIMING_BUILD (scratch/build_variants.sh passes it), and such an object exports
+// nbdt_timing_build, which makes nbdt/_C.py refuse the library unless NBDT_ALLOW_TIMING_BUILD=1 -- a stray -D in a
+// product build is a compile error, not a silently wrong gradient.
+#if !defined(NBDT_TIMING_BUILD) &&                                                                                    \
+    (defined(NBDT_WPP_GY_B128) || defined(NBDT_WPP_NO_EPI) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
+     defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) ||                    \
+     defined(NBDT_HALO_NO_ACCUMULATE) || defined(NBDT_DW_TARGET) || defined(NBDT_DW_U) || defined(NBDT_HEAD_SPB) ||    \
+     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) ||                       \
+     (defined(NBDT_HEAD_SKIP) && (NBDT_HEAD_SKIP + 0) != 0) || (defined(NBDT_PP_ABLATE) && (NBDT_PP_ABLATE + 0) != 0) || \
+     (defined(NBDT_PP_SCHED) && (NBDT_PP_SCHED + 0) != 0) || (defined(NBDT_PP_TIMING) && (NBDT_PP_TIMING + 0) != 0) ||  \
+     (defined(NBDT_WPP_TIMING) && (NBDT_WPP_TIMING + 0) != 0) || (defined(NBDT_RULES_TIMING) && (NBDT_RULES_TIMING + 0) != 0))
+#error "timing-experiment switch without -DNBDT_TIMING_BUILD: these switches change what the kernels compute (csrc/common.h)"
+#endif
+#ifdef NBDT_TIMING_BUILD
+extern "C" __attribute__((weak, used, visibility("default"))) int nbdt_timing_build() { return 1; }
+#endif
+
 namespace nbdt {
 
 extern thread_local char g_err[512];

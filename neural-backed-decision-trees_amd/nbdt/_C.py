@@ -161,6 +161,11 @@ def lib():
                 f"{_LIBPATH} is missing: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the NBDT hot path.")
         l = ctypes.CDLL(_LIBPATH)
+        # a timing-experiment build (csrc/common.h: -DNBDT_TIMING_BUILD + switches that skip or fake part of a kernel)
+        # computes wrong gradients by design: only the measurement scripts under scratch/ may load one
+        if hasattr(l, "nbdt_timing_build") and os.environ.get("NBDT_ALLOW_TIMING_BUILD") != "1":
+            raise NBDTHipError(f"{_LIBPATH} is a timing-experiment build (exports nbdt_timing_build): its kernels skip "
+                               "work on purpose.  Set NBDT_ALLOW_TIMING_BUILD=1 in a measurement script; never train with it.")
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(l, name)

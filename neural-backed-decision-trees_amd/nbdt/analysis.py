@@ -45,8 +45,10 @@ class _Phase:
     @contextlib.contextmanager
     def __call__(self, epoch):
         self._begin(epoch)
-        yield
-        self._finish(epoch)
+        try:
+            yield
+        finally:                 # like the reference's StartEndContext.__exit__ (analysis.py:77-78): end_* runs even when
+            self._finish(epoch)  # the body raises, so the analyzer's phase / epoch state never goes stale
 
 
 class Noop:
@@ -163,6 +165,9 @@ class DecisionRules(Noop):
         return 100.0 * self.correct / max(self._seen, 1)
 
     def start_test(self, epoch):
+        # The reference's override (analysis.py:221-222) does not check the epoch: a driver that evaluates without an
+        # enclosing start_epoch (an eval-only run) must not raise here.  Adopt the epoch instead of asserting it.
+        self.epoch = epoch
         super().start_test(epoch)
         self._hits, self._seen = None, 0
 

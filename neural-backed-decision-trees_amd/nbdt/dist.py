@@ -17,11 +17,22 @@ import torch.distributed as dist
 
 # RCCL's footprint on the chip, chosen HERE rather than left to its tuner: an all-reduce kernel is one thread block per
 # channel, and every such block holds a CU that a one-block-per-CU MFMA kernel of the backward pass then cannot use.
-# 8 channels (one per XCD) move the 146 MB of WRN-28-10 gradients in ~1.7 ms at the ~20 GB/s a channel sustains over
-# xGMI -- inside the ~11 ms of backward they overlap with -- and cost the MFMA kernels 8 of 256 CUs while buckets are
-# in flight (engine.backward -> ops.set_reserved_cus).  NBDT_RCCL_CHANNELS overrides; an NCCL_MAX_NCHANNELS already
-# in the environment wins.
+# 8 channels (one per XCD) move the 146 MB of WRN-28-10 gradients in ~1.7 ms at the ~20 GB/s a channel is ASSUMED to
+# sustain over xGMI -- inside the ~11 ms of backward they overlap with; at a third of that rate the exchange still ends
+# before backward does, because the largest bucket (stage 3, ~3/4 of the bytes) is ready first -- and cost the MFMA
+# kernels 8 of 256 CUs while buckets are in flight (engine.backward -> ops.set_reserved_cus).
+#
+# The bound is a DEFAULT, not a fact about the fabric: bench.py's `comm` object reports the exposed
+# all-reduce time next to this model, and every knob is overridable without touching code:
+#   NBDT_RCCL_CHANNELS=n   bound RCCL to n channels (n >= 1); NBDT_RCCL_CHANNELS=0: do not touch RCCL at all
+#   NCCL_MAX_NCHANNELS     already in the environment: wins over everything here (and is what the CU reservation uses)
+#   NCCL_MIN_NCHANNELS     RCCL raises its channel count to at least this; a minimum above the bound would make RCCL
+#                          ignore the bound, so the bound (and the CU reservation) is raised to it
+#   NBDT_RCCL_RESERVED_CUS CUs to keep free for the collective when its channel count is unknown (process group created
+#                          elsewhere, or NBDT_RCCL_CHANNELS=0); default UNKNOWN_CHANNELS_RESERVE
+# The variable caps every RCCL communicator of the process: a host program with other collectives sets its own value.
 DEFAULT_RCCL_CHANNELS = 8
+UNKNOWN_CHANNELS_RESERVE = 16        # CUs left to a collective whose channel count nobody bounded
 ASSUMED_GBPS_PER_CHANNEL = 20.0      # stated assumption until a multi-GPU node measures it (bench.py's `comm` object)
 RCCL = {"max_nchannels": None, "set_by": None}
 
@@ -32,13 +43,31 @@ def rccl_channels():
 
 
 def _bound_rccl_footprint():
-    if "NCCL_MAX_NCHANNELS" in os.environ:
-        RCCL.update(max_nchannels=int(os.environ["NCCL_MAX_NCHANNELS"]), set_by="NCCL_MAX_NCHANNELS (environment)")
+    env = os.environ
+    floor = int(env["NCCL_MIN_NCHANNELS"]) if env.get("NCCL_MIN_NCHANNELS", "").isdigit() else 0
+    if "NCCL_MAX_NCHANNELS" in env:
+        RCCL.update(max_nchannels=max(int(env["NCCL_MAX_NCHANNELS"]), floor), set_by="NCCL_MAX_NCHANNELS (environment)")
         return
-    n = int(os.environ.get("NBDT_RCCL_CHANNELS", DEFAULT_RCCL_CHANNELS))
-    os.environ["NCCL_MAX_NCHANNELS"] = str(n)           # read by RCCL when the communicator is created
-    RCCL.update(max_nchannels=n, set_by="NBDT_RCCL_CHANNELS" if "NBDT_RCCL_CHANNELS" in os.environ
-                else "nbdt.dist default")
+    n = int(env.get("NBDT_RCCL_CHANNELS", DEFAULT_RCCL_CHANNELS))
+    if n <= 0:                                          # opt-out: RCCL's tuner decides, the footprint is unknown
+        RCCL.update(max_nchannels=None, set_by="NBDT_RCCL_CHANNELS=0 (left to RCCL)")
+        return
+    by = "NBDT_RCCL_CHANNELS" if "NBDT_RCCL_CHANNELS" in env else "nbdt.dist default"
+    if floor > n:
+        n, by = floor, by + ", raised to NCCL_MIN_NCHANNELS"
+    env["NCCL_MAX_NCHANNELS"] = str(n)                  # read by RCCL when the communicator is created
+    RCCL.update(max_nchannels=n, set_by=by)
+
+
+def reserved_cus_for_rccl():
+    """CUs the one-block-per-CU kernels leave to RCCL's kernels: the channel bound IN EFFECT (ours, or an
+    NCCL_MAX_NCHANNELS the process group was created under), else a stated reserve for an unbounded communicator."""
+    n = rccl_channels()
+    if n is None and os.environ.get("NCCL_MAX_NCHANNELS", "").isdigit():
+        n = int(os.environ["NCCL_MAX_NCHANNELS"])        # group created elsewhere, under the caller's own bound
+    if n is None:
+        n = int(os.environ.get("NBDT_RCCL_RESERVED_CUS", UNKNOWN_CHANNELS_RESERVE))
+    return max(0, min(int(n), 64))
 
 
 def allreduce_model_ms(nbytes, world, channels=None, gbps_per_channel=ASSUMED_GBPS_PER_CHANNEL):
@@ -93,7 +122,7 @@ class GradComm:
         self._work = []
         # CUs the collective's kernels occupy while a bucket is in flight (one block per channel); 0 for gloo / 1 rank
         rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" and (self.world_size > 1 or self.force)
-        self.reserved_cus = (rccl_channels() or DEFAULT_RCCL_CHANNELS) if rccl else 0
+        self.reserved_cus = reserved_cus_for_rccl() if rccl else 0
 
     def describe(self, nbytes):
         """What bench.py puts into its `comm` object about the exchange of `nbytes` per rank."""

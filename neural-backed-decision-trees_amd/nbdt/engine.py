@@ -125,8 +125,16 @@ class Conv:
         """(forward desc, dgrad descs, accumulating dgrad descs, wgrad desc) for one input geometry."""
         args = (B, Hi, Wi, self.cin, self.cout, self.k, self.stride)
         plain_dgrad = None if (self.k == 1 and self.stride == 2) else ops.conv_dgrad_descs(*args, accumulate=False)
-        return (ops.conv_fwd_desc(*args), plain_dgrad, ops.conv_dgrad_descs(*args, accumulate=True),
+        plan = (ops.conv_fwd_desc(*args), plain_dgrad, ops.conv_dgrad_descs(*args, accumulate=True),
                 ops.conv_wgrad_desc(*args))
+        # what the launch timers count as a launch's flops: the layer's REAL channels, not the 32-padded ones the kernels
+        # multiply (16 -> 32 for WRN's first unit): fwd / wgrad (cin, cout), dgrad (cout, cin) -- ops.desc_flops
+        for d in (plan[0], plan[3]):
+            d.flop_channels = (self.cin_real, self.cout_real)
+        for descs in (plan[1], plan[2]):
+            for d in descs or ():
+                d.flop_channels = (self.cout_real, self.cin_real)
+        return plan
 
     def numel(self):
         return self.cout * self.taps * self.cin
@@ -295,16 +303,30 @@ class _Engine:
         return self._scratch
 
     def slot_pair(self, C):
-        """(slots, slots_other) for ops.bn_bwd_cus' two-launch form: two zeroed 32-slot buffers PER CHANNEL COUNT that
-        swap roles at every call (the pass leaves the one it summed into dirty and zeroes the other one -- for ITS
-        channel count, hence one pair per C).  Every user is a launch on the caller's stream, in program order."""
+        """(slots, slots_other) for ops.bn_bwd_cus' two-launch form: two 32-slot buffers PER CHANNEL COUNT that swap roles
+        at every call (the pass leaves the one it summed into dirty and zeroes the other one -- for ITS channel count, hence
+        one pair per C).  Every user is a launch on the caller's stream, in program order.  The kernel's contract is
+        "`slots` is zero on entry": a step makes an ODD number of calls per channel count (2n-1 for a WRN stage), so the
+        pair does not return to its starting state by itself -- backward() calls reset_slot_pairs() first, which makes
+        every step (and every captured graph of one) start from (zero, zero) whatever ran before it."""
         pairs = self.__dict__.setdefault("_slot_pairs", {})
         if C not in pairs:
             n = ops.BN_SLOTS * 2 * C
-            pairs[C] = [torch.zeros(n, device=self.device), torch.zeros(n, device=self.device), 0]
+            # [buffer 0, buffer 1, index of the buffer the LAST call summed into (dirty), or -1: both are zero]
+            pairs[C] = [torch.zeros(n, device=self.device), torch.zeros(n, device=self.device), -1]
         pair = pairs[C]
-        pair[2] ^= 1
-        return pair[pair[2]], pair[pair[2] ^ 1]
+        use = 0 if pair[2] != 0 else 1          # sum into the buffer the last call zeroed
+        pair[2] = use
+        return pair[use], pair[use ^ 1]
+
+    def reset_slot_pairs(self):
+        """Zero the one dirty buffer of every slot pair (a stream-ordered fill on the caller's stream) so that the next
+        slot_pair() call finds (zero, zero).  Called at the top of backward(): a hipGraph of a step bakes the pointers
+        in, and without this replay k+1's first call per channel count summed into what replay k's last call left."""
+        for pair in self.__dict__.get("_slot_pairs", {}).values():
+            if pair[2] >= 0:
+                pair[pair[2]].zero_()
+                pair[2] = -1
 
     def partials(self, out):
         """Workspace for the conv-epilogue BN partial sums of a padded [B,H+2,W+2,C] output."""
@@ -806,6 +828,7 @@ class WRNEngine(_Engine):
         self.join_side_stream()      # dgrad weight copies (built on the second stream after the last update)
         if self._cu_share is not None and not self._share_calibrated:
             self.calibrate_cu_share(comm)      # once per set_cu_share(): keep the sharing only if it is faster here
+        self.reset_slot_pairs()      # the confined BatchNorm backward's slot buffers start every step from (zero, zero)
         two_streams = self._side is not None and self._overlap
         buckets = self.grad_buckets() if comm is not None else None
         st = self.store
@@ -1182,10 +1205,12 @@ class GraphedStep:
     stream every C-ABI launch already uses) and replayed with one host call.
 
     The step is a fixed sequence of ~130 (ResNet18) to ~700 (EfficientNet-B0) launches with no host
-    synchronisation, so it captures as is.  Measured on MI355X (scratch/bench_graph.py): replay and eager
-    launching take the same time for every configuration tried (ResNet18 B=128: 3.89 vs 3.89 ms; WRN-28-10
-    B=512: 21.8 vs 21.8 ms) -- the ctypes launch path costs ~5 us per kernel and the CPU stays ahead of the GPU
-    (2.2 ms of enqueue for a 21 ms step), so this is latency insurance for slower hosts, not a speed-up.  The learning rate and the dropout
+    synchronisation, so it captures as is.  Measured on MI355X (scratch/bench_graph.py, profiles/r04_graph.txt):
+    replay is 4-8 % SLOWER than eager launching for every configuration tried (ResNet18 B=128: 3.35 vs 3.13 ms;
+    WRN-28-10 B=512: 18.42 vs 17.40 ms; in round 2, before the two-stream schedule, the two were equal at 21.8 ms) --
+    the ctypes launch path costs ~5 us per kernel and the CPU stays ahead of the GPU (2.2 ms of enqueue for a 17 ms
+    step), while the graph serialises the cross-stream edges the eager schedule overlaps.  So this is latency insurance
+    for slower hosts, not a speed-up, and bench.py does not use it.  The learning rate and the dropout
     seed are kernel arguments baked into the graph: build one GraphedStep per learning rate, and do not use it
     for models with dropout.  So are the loss weights and the device pointers of the hierarchy: a replay after
     ``criterion.set_epoch`` changed the weights (--tswe / --xwe schedules) or after the hierarchy was re-induced

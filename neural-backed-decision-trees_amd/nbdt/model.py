@@ -128,6 +128,29 @@ class HardEmbeddedDecisionRules(EmbeddedDecisionRules):
         outputs_sub = cls.get_node_logits(outputs, node)
         return selector, outputs_sub, targets_sub
 
+    @classmethod
+    def traverse_tree(cls, wnid_to_outputs, tree):
+        """reference :146-187 -- (predicted classes, decisions) from a dict of per-node outputs a caller built or edited
+        itself (``forward_nodes`` / ``get_all_node_outputs``).  API parity only: ``forward`` / ``forward_with_decisions``
+        never build the dict -- they are one fused kernel launch -- so this host walk is for analysis code that
+        intervenes on node outputs.  A sample whose walk reaches an inner node missing from the dict raises KeyError
+        (the reference dereferences ``None`` there)."""
+        first = wnid_to_outputs[tree.inodes[0].wnid]["logits"]
+        host = {w: (o["preds"].detach().cpu().tolist(), o["probs"].detach().cpu(), o["entropy"].detach().cpu())
+                for w, o in wnid_to_outputs.items()}
+        preds, decisions = [], []
+        for i in range(int(first.shape[0])):
+            node, walk = tree.root, [{"node": tree.root, "name": "root", "prob": 1, "entropy": 0}]
+            while not node.is_leaf():
+                choice, probs, entropy = host[node.wnid]
+                k = int(choice[i])
+                node = node.children[k]
+                walk.append({"node": node, "name": node.name, "prob": float(probs[i][k]), "next_index": k,
+                             "entropy": float(entropy[i])})
+            preds.append(tree.wnid_to_class_index[node.wnid])
+            decisions.append(walk)
+        return torch.tensor(preds, dtype=torch.long, device=first.device), decisions
+
     def predicted_to_logits(self, predicted):
         if self.I.device != predicted.device:
             self.I = self.I.to(predicted.device)
@@ -176,6 +199,20 @@ class HardEmbeddedDecisionRules(EmbeddedDecisionRules):
 
 class SoftEmbeddedDecisionRules(EmbeddedDecisionRules):
     """Path-probability product over the hierarchy (reference :206-273); differentiable."""
+
+    @classmethod
+    def traverse_tree(cls, wnid_to_outputs, tree):
+        """reference :208-242 -- class probabilities as the product, over the inner nodes, of the probability of the
+        child each class lies under, from a caller-built dict of per-node outputs.  API parity only (``forward`` is the
+        fused kernel); plain tensor ops on whatever device the dict's tensors live on."""
+        first = wnid_to_outputs[tree.inodes[0].wnid]["logits"]
+        class_probs = torch.ones((first.shape[0], len(tree.classes)), device=first.device)
+        for node in tree.inodes:
+            pairs = [(old, new) for new, olds in node.child_index_to_class_index.items() for old in olds]
+            olds, news = [p[0] for p in pairs], [p[1] for p in pairs]
+            assert len(set(olds)) == len(olds), "a class under two children of one node"
+            class_probs[:, olds] *= wnid_to_outputs[node.wnid]["probs"][:, news].to(class_probs.dtype)
+        return class_probs
 
     def forward_with_decisions(self, outputs):
         """reference :244-266.  The reference reports sample 0's node probabilities for every

@@ -236,7 +236,7 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
         return
     ev = None
     if _timer is not None and _timer.wants("conv_igemm"):
-        flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
+        flops = desc_flops(desc)
         ev = _timer.bracket("conv_igemm", flops, inp.device)
         ev[0].record()
     if bn_scratch is None:
@@ -250,6 +250,14 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
         _timer.count(last_igemm_kernel())
 
 
+def desc_flops(desc):
+    """Algorithmic flops of one conv / data-gradient / weight-gradient launch: 2 x pixels x taps x cin x cout with the
+    layer's REAL channel counts when the engine attached them (desc.flop_channels; the kernels multiply channels padded
+    to 32 -- WRN's first unit 16 -> 32 -- and round 4's roofline counted those, +0.5 %), else the descriptor's own."""
+    cin, cout = getattr(desc, "flop_channels", (desc.cin, desc.cout))
+    return 2.0 * desc.B * desc.gh * desc.gw * desc.ntaps * cin * cout
+
+
 def conv_igemm_multi(descs, inp, w_bf16, out):
     """The launches of `descs` (<= 4, same operands: the parity classes of a strided 3x3 data gradient) in one grid."""
     if _ref(inp):
@@ -259,7 +267,7 @@ def conv_igemm_multi(descs, inp, w_bf16, out):
     arr = (ConvDesc * len(descs))(*descs)
     ev = None
     if _timer is not None and _timer.wants("conv_igemm"):
-        flops = sum(2.0 * d.B * d.gh * d.gw * d.cout * d.ntaps * d.cin for d in descs)
+        flops = sum(desc_flops(d) for d in descs)
         ev = _timer.bracket("conv_igemm", flops, inp.device)
         ev[0].record()
     check(lib().nbdt_conv_igemm_multi(arr, len(descs), ptr(inp), ptr(w_bf16), ptr(out), stream_ptr(inp.device)))
@@ -273,7 +281,7 @@ def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, part
     _no_ref(inp, "conv_igemm_bnbwd (fused BatchNorm-backward sums): use the split or the unfused schedule")
     ev = None
     if _timer is not None and _timer.wants("conv_igemm"):
-        flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
+        flops = desc_flops(desc)
         ev = _timer.bracket("conv_igemm", flops, inp.device)
         ev[0].record()
     check(lib().nbdt_conv_igemm_bnbwd(ctypes.byref(desc), ptr(inp), ptr(w_bf16), ptr(out), ptr(bn_x), ptr(mean),
@@ -337,7 +345,7 @@ def conv_wgrad(desc, x, gy, dw, cu_budget=0):
         return
     ev = None
     if _timer is not None and _timer.wants("conv_wgrad"):
-        flops = 2.0 * desc.B * desc.gh * desc.gw * desc.cout * desc.ntaps * desc.cin
+        flops = desc_flops(desc)
         ev = _timer.bracket("conv_wgrad", flops, x.device)
         ev[0].record()
     check(lib().nbdt_conv_wgrad(ctypes.byref(desc), ptr(x), ptr(gy), ptr(dw), stream_ptr(x.device)))

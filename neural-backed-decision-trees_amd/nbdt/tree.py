@@ -117,6 +117,24 @@ class Node:
     def is_root(self):
         return len(self.pred) == 0
 
+    # thin delegates a reference subclass may call (reference nbdt/tree.py:96-97, 127-139); the kernels never do
+    def get_leaves(self):
+        """wnids of the leaves under this node, in the Tree's own order."""
+        under = self.tree._leaves_under(self.wnid)
+        return [w for w in self.tree._order if w in under]
+
+    def build_classes(self):
+        return list(self.classes)
+
+    @property
+    def class_counts(self):
+        """Number of original classes under each child."""
+        return [len(olds) for _, olds in sorted(self.child_index_to_class_index.items())]
+
+    @staticmethod
+    def dim(nodes):
+        return sum(node.num_classes for node in nodes)
+
     def wnid_to_class_index(self, wnid):
         return self.tree.wnid_to_class_index[wnid]
 
@@ -267,6 +285,10 @@ class Tree:
             if node.is_root():
                 return node
         raise UserWarning("Should not be reachable. Tree should always have root")
+
+    def get_wnid_to_node(self):
+        """reference nbdt/tree.py:209-213: a fresh {wnid: Node} map (load_hierarchy keeps its own in wnid_to_node)."""
+        return {w: Node(self, w) for w in self._order}
 
     @property
     def flat(self):

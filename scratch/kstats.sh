@@ -2,7 +2,7 @@
 # per-kernel average durations of the serial (single-stream) training step, for A/B of kernel variants
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for V in "$@"; do
-  if [ "$V" = base ]; then L=""; else L="NBDT_HIP_LIB=$R/scratch/variants/libnbdt_$V.so"; fi
+  if [ "$V" = base ]; then L=""; else L="NBDT_ALLOW_TIMING_BUILD=1 NBDT_HIP_LIB=$R/scratch/variants/libnbdt_$V.so"; fi
   env $L rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$V -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-other-configs --agreement-n 0 --no-overlap > /tmp/ks_$V.log 2>&1
   echo "== $V"; python - <<PY
 import csv,glob

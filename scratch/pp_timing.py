@@ -1,4 +1,4 @@
-"""Per-segment cycle sums of the ping-pong igemm kernel (NBDT_PP_TIMING build): run with NBDT_HIP_LIB=scratch/variants/libnbdt_tim.so"""
+"""Per-segment cycle sums of the ping-pong igemm kernel (NBDT_PP_TIMING build): run with NBDT_ALLOW_TIMING_BUILD=1 NBDT_HIP_LIB=scratch/variants/libnbdt_tim.so"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nbdt_path; nbdt_path.add()

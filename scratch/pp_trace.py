@@ -1,4 +1,4 @@
-"""Timeline of the ping-pong igemm kernel per CU (NBDT_PP_TIMING=2 build): run with NBDT_HIP_LIB=scratch/variants/libnbdt_trace.so.
+"""Timeline of the ping-pong igemm kernel per CU (NBDT_PP_TIMING=2 build): run with NBDT_ALLOW_TIMING_BUILD=1 NBDT_HIP_LIB=scratch/variants/libnbdt_trace.so.
 Four s_memtime stamps per block (entry, K loop start, epilogue start, stores acknowledged) + HW_ID/XCC_ID; blocks are
 grouped by CU and sorted by entry time: the gap between one block's end and the next block's entry is dispatch cost."""
 import ctypes, os, sys

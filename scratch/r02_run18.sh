@@ -6,12 +6,12 @@ timeout 600 python -m pytest tests/test_backbone_gpu.py -x -q -k "fold or statis
 for i in 1 2 3; do
   for L in scratch/variants/libnbdt_oldfold.so ""; do
     echo "== lib ${L:-in-tree}"
-    NBDT_HIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --agreement-n 0 --no-kernel-timer --steps 40 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')})"
+    NBDT_ALLOW_TIMING_BUILD=1 NBDT_HIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --agreement-n 0 --no-kernel-timer --steps 40 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')})"
   done
 done
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for V in oldfold base; do
-  if [ "$V" = base ]; then L=""; else L="NBDT_HIP_LIB=$R/scratch/variants/libnbdt_$V.so"; fi
+  if [ "$V" = base ]; then L=""; else L="NBDT_ALLOW_TIMING_BUILD=1 NBDT_HIP_LIB=$R/scratch/variants/libnbdt_$V.so"; fi
   env $L rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$V -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --agreement-n 0 --no-overlap > /tmp/ks_$V.log 2>&1
   echo "== $V"; python - <<PY
 import csv,glob

@@ -81,3 +81,27 @@ def test_a_hook_for_another_epoch_is_an_error():
     with pytest.raises(ValueError):
         analysis.DecisionRules.__init__(analysis.DecisionRules.__new__(analysis.DecisionRules), dataset="CIFAR10",
                                         hierarchy="induced-ResNet18", metric="top3")
+
+
+def test_an_exception_inside_a_phase_still_ends_it():
+    """the reference's StartEndContext.__exit__ (analysis.py:77-78) calls end_* whatever happened in the body."""
+    r = Recorder()
+    with pytest.raises(RuntimeError, match="boom"):
+        with r.epoch_context(2):
+            @r.train_function
+            def train(epoch):
+                raise RuntimeError("boom")
+            train(2)
+    assert [c[0] for c in r.calls] == ["start_epoch", "start_train", "end_train", "end_epoch"]
+    assert r.phase is None and r.calls[2] == ("end_train", 2, None)
+
+
+def test_decision_rules_start_test_adopts_the_epoch_like_the_reference():
+    """Reference analysis.py:221-222: DecisionRules.start_test does not assert the epoch (an eval-only driver never called
+    start_epoch).  No kernel runs here: the object is built without its rules."""
+    d = analysis.DecisionRules.__new__(analysis.DecisionRules)
+    analysis.Noop.__init__(d, classes=("a", "b"))
+    d.best_accuracy, d.verbose = 0.0, False
+    d.start_test(7)                      # no enclosing start_epoch: must not raise
+    assert d.epoch == 7 and d.phase == "test"
+    d.end_test(7)

@@ -552,6 +552,18 @@ def test_stem(cout, cpad):
                                rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("cout,cpad", [(12, 32), (75, 96), (80, 96)])
+def test_stem_wgrad_refuses_widths_its_kernel_does_not_cover(cout, cpad):
+    """include/nbdt_hip.h: cout_real a multiple of 8, <= 72 (the contract narrowed in round 4; say so loudly)."""
+    from nbdt._C import NBDTHipError
+    img = torch.randn(2, 3, 8, 8, device=DEV)
+    gp = ops.padded(2, 8, 8, cpad, DEV)
+    dw = torch.zeros(cout, 27, device=DEV)
+    with pytest.raises(NBDTHipError, match="stem wgrad supports"):
+        ops.stem_wgrad(img, gp, dw, cout)
+    assert dw.abs().max().item() == 0
+
+
 def test_sgd_matches_torch_optim():
     n = 100003
     g = torch.Generator().manual_seed(41)

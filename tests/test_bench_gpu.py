@@ -70,3 +70,30 @@ def test_bench_two_rank_branch_runs_on_one_gpu_over_gloo():
     assert len(c["cu_share_per_rank"]) == 2 and c["cu_share_per_rank"][0] == c["cu_share_per_rank"][1]
     assert abs(d["value"] - 128 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
     assert "roofline" in d and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("ranks", [4, 8])
+def test_bench_n_rank_branch_at_the_driver_rank_counts(ranks):
+    """bucket order, `broadcast_flag`, max-over-ranks timing and the `comm` object had only ever seen
+    2 ranks.  The driver's scaling run uses 4 and 8: the same branch with that many ranks, all on this box's GPU over
+    gloo (one rank per GPU over RCCL when the box has them).  Every rank applies the same all-reduced gradient, so the
+    replicas must be bit-identical after the steps -- bench.py gathers two checksums of the weights per rank."""
+    import torch
+    multi = torch.cuda.device_count() >= ranks
+    extra = [] if multi else ["--backend", "gloo", "--share-gpu"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3",
+                          "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--agreement-n", "0",
+                          "--no-kernel-timer", "--no-other-configs"] + extra,
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["global_batch"] == 64 * ranks
+    assert d["config"]["parallelism"] == f"dp{ranks}" and d["scaling"] == "weak"
+    c = d["comm"]
+    assert c["ranks"] == ranks and c["buckets"] == 3 and c["backend"] == ("nccl" if multi else "gloo")
+    assert len(c["cu_share_per_rank"]) == ranks and len(set(c["cu_share_per_rank"])) == 1      # rank 0 decided for all
+    assert len(c["replica_checksums"]) == ranks and c["replicas_identical"], c["replica_checksums"]
+    assert c["replica_checksums"][0][1] > 0
+    assert abs(d["value"] - 64 * ranks * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]

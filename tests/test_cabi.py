@@ -113,3 +113,27 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "nbdt_oracle" not in src and "torch_models" not in src, f
+
+
+def test_timing_experiment_switches_do_not_compile_into_a_product_build(tmp_path):
+    """-DNBDT_WPP_NO_EPI, -DNBDT_PP_KFRAC5=3, -DNBDT_PP_ABLATE=4 ... skip or fake part of a kernel (wrong
+    gradients by design).  csrc/common.h turns any of them into a compile error unless -DNBDT_TIMING_BUILD is given too,
+    and a timing build exports nbdt_timing_build, which nbdt._C.lib() refuses without NBDT_ALLOW_TIMING_BUILD=1."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "common.h"\nint main() { return 0; }\n')
+    base = [hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I",
+            os.path.join(nbdt_path.PKG_DIR, "csrc"), str(src)]
+    for switch in ("-DNBDT_WPP_NO_EPI", "-DNBDT_PP_KFRAC5=3", "-DNBDT_PP_ABLATE=4", "-DNBDT_HEAD_SKIP=1"):
+        bad = subprocess.run(base + [switch], capture_output=True, text=True)
+        assert bad.returncode != 0 and "NBDT_TIMING_BUILD" in bad.stderr, (switch, bad.stderr[-500:])
+        ok = subprocess.run(base + [switch, "-DNBDT_TIMING_BUILD"], capture_output=True, text=True)
+        assert ok.returncode == 0, (switch, ok.stderr[-500:])
+    assert subprocess.run(base + ["-DNBDT_PP_ABLATE=0"], capture_output=True, text=True).returncode == 0
+    # the shipped library is not a timing build
+    import ctypes
+    assert not hasattr(ctypes.CDLL(_C.libpath()), "nbdt_timing_build")

@@ -154,6 +154,24 @@ def test_rccl_channel_bound_and_allreduce_model(monkeypatch):
     assert ndist.allreduce_model_ms(nbytes, 1) == 0.0
     assert abs(ndist.allreduce_model_ms(nbytes, 8, channels=8) - 1e3 * 1.75 * nbytes / 160e9) < 1e-9
     assert abs(ndist.allreduce_model_ms(nbytes, 2, channels=8) - 1e3 * nbytes / 160e9) < 1e-9
+    # the knobs of ADVICE r4: opt-out, a minimum above the bound, reservation from the bound actually in effect
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.setenv("NBDT_RCCL_CHANNELS", "0")              # leave RCCL alone: nothing exported, footprint unknown
+    ndist._bound_rccl_footprint()
+    assert "NCCL_MAX_NCHANNELS" not in os.environ and ndist.rccl_channels() is None
+    assert ndist.reserved_cus_for_rccl() == ndist.UNKNOWN_CHANNELS_RESERVE
+    monkeypatch.setenv("NBDT_RCCL_RESERVED_CUS", "24")
+    assert ndist.reserved_cus_for_rccl() == 24
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "12")             # a group created elsewhere under the caller's own bound
+    assert ndist.reserved_cus_for_rccl() == 12
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
+    monkeypatch.delenv("NBDT_RCCL_CHANNELS")
+    monkeypatch.setenv("NCCL_MIN_NCHANNELS", "12")             # RCCL would ignore a bound below its minimum
+    ndist._bound_rccl_footprint()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "12" and ndist.reserved_cus_for_rccl() == 12
+    assert "NCCL_MIN_NCHANNELS" in ndist.RCCL["set_by"]
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS")
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS")
     ndist.RCCL.update(max_nchannels=None, set_by=None)
     # a gloo / single-process GradComm holds no CUs
     comm = ndist.GradComm()

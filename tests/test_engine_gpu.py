@@ -529,6 +529,43 @@ def test_hipgraph_captures_the_wrn_step_with_cu_sharing_and_lagged_events():
                 cg.capture_end()
 
 
+def test_hipgraph_replays_start_the_confined_bn_backward_from_zeroed_slots():
+    """nbdt_bn_bwd_cus sums into `slots`, which must be zero on entry, and leaves it dirty; the engine
+    alternates two buffers per channel count, and a WRN step makes an ODD number of calls per channel count (2n-1), so a
+    captured graph -- pointers baked in -- used to start replay k+1 on the buffer replay k left dirty: dsum / dgamma /
+    dbeta / gx of every stage's last bn2 doubled from the second replay on.  backward() now resets the pairs first.
+    lr = 0 (parameters never move): after EVERY replay each BatchNorm's backward sums must equal the eager engine's."""
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-wrn28_10_cifar10")
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(64, 3, 32, 32, generator=g).to(DEV) for _ in range(4)]
+    ys = [torch.randint(0, 10, (64,), generator=g).to(DEV) for _ in range(4)]
+    eager = E.WRNEngine(num_classes=10, blocks=16, width_factor=4, device=DEV, seed=5)
+    graphed = E.WRNEngine(num_classes=10, blocks=16, width_factor=4, device=DEV, seed=5)
+    for e in (eager, graphed):
+        e.set_cu_share(47.0, calibrate=False)
+    assert graphed.fuse_bn_fold                         # the two-launch form with the slot pairs is the default
+    step = E.GraphedStep(graphed, crit, xs[0], ys[0], lr=0.0, momentum=0.0, weight_decay=0.0, warmup=1)
+    assert getattr(graphed, "_slot_pairs", None), "the captured step did not use the slot pairs"
+    worst = 0.0
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        E.train_step(eager, crit, x, y, 0.0, 0.0, 0.0)
+        step(x, y)
+        torch.cuda.synchronize()
+        for be, bg in zip(eager.bns, graphed.bns):
+            ref = be.dsum.double()
+            assert torch.isfinite(ref).all() and torch.isfinite(bg.dsum).all(), (k, be.name)
+            rel = ((bg.dsum.double() - ref).norm() / ref.norm().clamp_min(1e-20)).item()
+            worst = max(worst, rel)
+            assert rel < 2e-2, (k, be.name, rel)
+    print(f"BatchNorm backward sums, graph replay vs eager over {len(xs)} replays: worst relative difference {worst:.2e}")
+    # and with lr > 0 the replays train like eager steps do (same batch: the loss falls by a similar amount)
+    step = E.GraphedStep(graphed, crit, xs[0], ys[0], lr=0.02, momentum=0.0, weight_decay=0.0, warmup=1)
+    lg = [step(xs[0], ys[0]).item() for _ in range(4)]
+    E.train_step(eager, crit, xs[0], ys[0], 0.02, 0.0, 0.0)        # (the graphed engine's warm-up step)
+    le = [E.train_step(eager, crit, xs[0], ys[0], 0.02, 0.0, 0.0).item() for _ in range(4)]
+    assert lg[-1] < lg[0] and abs(lg[-1] - le[-1]) < 0.25 * abs(le[0] - le[-1]) + 3e-2 * abs(le[-1]), (lg, le)
+
+
 @pytest.mark.parametrize("B", [1, 3, 5, 9])
 def test_ragged_batch_sizes_match_the_oracle(B, pkg_dir):
     """Pixel tiles that straddle the end of the batch (M not a multiple of 256 / 512 pixels, tiles covering more

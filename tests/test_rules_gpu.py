@@ -238,6 +238,14 @@ def test_module_api_matches_reference_contracts(pkg_dir):
     assert torch.equal(H, H2) and len(decisions) == 16 and decisions[0][0]["name"] == "root"
     for dec, p in zip(decisions, H.argmax(1).tolist()):
         assert dec[-1]["node"].wnid == soft.rules.tree.wnids_leaves[p]
+    # the traverse_tree classmethods (reference model.py:146, :208) on a caller-built dict == the fused kernels
+    w2o = hard.rules.forward_nodes(z)
+    tp, tdec = HardEmbeddedDecisionRules.traverse_tree(w2o, hard.rules.tree)
+    assert torch.equal(tp, H.argmax(1)) and tp.device == z.device
+    assert [[s["name"] for s in d] for d in tdec] == [[s["name"] for s in d] for d in decisions]
+    assert all(abs(a["prob"] - b["prob"]) < 1e-6 for da, db in zip(tdec, decisions) for a, b in zip(da, db))
+    tP = SoftEmbeddedDecisionRules.traverse_tree(soft.rules.forward_nodes(z), soft.rules.tree)
+    np.testing.assert_allclose(tP.detach().cpu().numpy(), P.detach().cpu().numpy(), rtol=2e-5, atol=1e-6)
     Ps, sdec = soft.forward_with_decisions(x)
     assert len(sdec) == 16 and abs(np.prod([s["prob"] for s in sdec[3]]) - Ps[3].max().item()) < 1e-5
     with pytest.raises(NotImplementedError):

@@ -51,6 +51,13 @@ def test_reference_api_surface():
     for leaf, path in steps.items():
         assert path[0]["node"] is root and path[-1]["next_index"] == -1
         assert path[-1]["node"].wnid == leaf
+    # thin delegates of the reference's Node / Tree (tree.py:96-139, 209-213)
+    assert sorted(root.get_leaves()) == sorted(tree.wnids_leaves) and sum(root.class_counts) == 10
+    assert root.build_classes() == root.classes and len(root.classes) == 2
+    fresh = tree.get_wnid_to_node()
+    assert set(fresh) == set(tree.wnid_to_node) and fresh[root.wnid] is not root
+    assert fresh[root.wnid].child_index_to_class_index == root.child_index_to_class_index
+    assert type(root).dim(tree.inodes) == sum(n.num_classes for n in tree.inodes)
     # default hierarchy resolution (nbdt/utils.py:62-71)
     assert Tree("CIFAR100").path_graph.endswith("hierarchies/CIFAR100/graph-induced.json")
     with pytest.raises(FileNotFoundError):

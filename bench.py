@@ -82,6 +82,60 @@ def pmc_traffic(launches_per_step):
     return (round(b / n) if n else None), "profiles/" + fname
 
 
+def attainable(dev):
+    """What the matrix pipes deliver on THIS box, measured right after the timed loop, so that a
+    kernel's distance from the 2.5 PFLOP/s spec splits into power / clock and schedule:
+
+      mfma_stream   register-only v_mfma_f32_32x32x16_bf16 stream, one 512-thread block per CU (two waves per SIMD like the
+                    8-wave kernels), per-lane / per-instruction varying operands (csrc/probe.hip): no memory at all --
+                    what is missing to 2.5 PF here is power / clock, nothing a schedule can recover;
+      attainable    the dominant kernel's OWN K loop in steady state: conv3x3_pp_kernel<5,false,0,8> -- the kernel of the
+                    plain data gradients -- on a synthetic 3x3 conv with 5120 input channels (160 K chunks x 9 taps = 1440
+                    K steps per 512-pixel tile instead of 45; 256 tiles, one per CU): per K step exactly the production
+                    mix (20 MFMA 32x32x16, 14 ds_read_b128, the step's LDS-DMA pieces, the two barriers, the address
+                    arithmetic in the MFMA shadow) with exactly the real dependencies, prologue + epilogue < 4 % of the
+                    launch.  mfma_stream - attainable = what the loop's own schedule + its memory instructions cost;
+                    attainable - achieved = what tile prologues, epilogues and launch boundaries cost."""
+    from nbdt import ops
+    from nbdt._C import lib, check, ptr
+    from nbdt.ops import stream_ptr
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    sink = torch.zeros(4, device=dev)
+    blocks, iters = 256, 6000
+    t = timed(lambda: check(lib().nbdt_probe_mfma_stream(blocks, iters, ptr(sink), stream_ptr(dev))), 3)
+    stream_tf = blocks * 8 * iters * 16 * 32768.0 / t / 1e12
+    B, H, cin, cout = 128, 32, 5120, 160
+    x = ops.padded(B, H, H, cin, dev)
+    ops.interior(x).normal_()
+    wb = (torch.randn(cout, 9, cin, device=dev) * 0.02).to(torch.bfloat16)
+    wt = ops.weight_tiles(wb)
+    out = ops.padded(B, H, H, cout, dev)
+    d = ops.conv_fwd_desc(B, H, H, cin, cout, 3, 1)
+    d.w_tiled = wt.data_ptr()
+    d.wide_tile = 2                                       # the 512-pixel ping-pong kernel or an error, never a fallback
+    t = timed(lambda: ops.conv_igemm(d, x, wb, out), 3)
+    kernel = ops.last_igemm_kernel()
+    loop_tf = 2.0 * B * H * H * cout * 9 * cin / t / 1e12
+    del x, wb, wt, out
+    return {"mfma_stream": round(stream_tf, 1), "attainable": round(loop_tf, 1), "attainable_kernel": kernel,
+            "attainable_how": "steady-state K loop of the dominant kernel: the same conv3x3_pp_kernel<5,false,0,8> on a "
+                              "synthetic 128x32x32 conv with 5120 input channels (1440 K steps per tile, 256 tiles, one "
+                              "per CU; 1.93 PFLOP per launch), HIP events over 3 launches after the timed loop; "
+                              "mfma_stream = register-only 32x32x16 bf16 MFMA stream on 256 CUs x 8 waves "
+                              "(nbdt_probe_mfma_stream): the power / clock ceiling"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: become the launcher (one rank per GPU, RCCL)."""
     import socket
@@ -271,6 +325,8 @@ def main():
                          "tensors, so `--gpus 2 --backend gloo --share-gpu` runs the N-rank branch on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on cuda:0 (tests on a 1-GPU box)")
     ap.add_argument("--agreement-n", type=int, default=512, help="images in the prediction-agreement check (0: skip)")
+    ap.add_argument("--no-attainable", action="store_true",
+                    help="skip the two probes behind roofline.attainable / roofline.mfma_stream (~0.1 s of GPU time)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the <= 1 s measurements of the other BASELINE.json configurations (`other_configs`)")
     args = ap.parse_args()
@@ -419,6 +475,16 @@ def main():
                                "measured_over": f"{roof_steps} steps continuing the timed loop, HIP events "
                                                 "around every launch on the launch stream, weight-gradient "
                                                 "stream joined (no concurrent kernel)"}
+            if world == 1 and not args.no_attainable:
+                try:
+                    a = attainable(dev)
+                    out["roofline"].update(a)
+                    out["roofline"]["frac_of_attainable"] = round(k["tflops"] / a["attainable"], 4)
+                    out["roofline"]["attainable_frac_of_peak"] = round(a["attainable"] / PEAK_BF16_TFLOPS, 4)
+                    out["roofline"]["mfma_stream_frac_of_peak"] = round(a["mfma_stream"] / PEAK_BF16_TFLOPS, 4)
+                except Exception as exc:          # a probe must never cost the bench line
+                    out["roofline"]["attainable"] = None
+                    out["roofline"]["attainable_error"] = repr(exc)[:300]
         w = summ.get("conv_wgrad")
         if w:
             out["roofline_wgrad"] = {"bound": "mfma",

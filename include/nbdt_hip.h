@@ -454,6 +454,12 @@ int nbdt_linear_bwd(const float* x, const float* w, const float* gz, int32_t B, 
 int nbdt_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float momentum,
                   float weight_decay, float grad_scale, void* p_bf16, int32_t zero_grad, void* stream);
 
+/* ------------------------------------------------------------------ measurement probe (not on the product path) */
+/* A register-only stream of independent v_mfma_f32_32x32x16_bf16 on `blocks` CUs (one 512-thread block each, two waves
+ * per SIMD): every wave issues iters x 16 of them (x 32768 flop).  bench.py times the launch for `roofline.mfma_stream`
+ * -- the power / clock ceiling of the matrix pipes on the box the bench runs on (csrc/probe.hip).  sink: >= 1 float. */
+int nbdt_probe_mfma_stream(int32_t blocks, int32_t iters, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

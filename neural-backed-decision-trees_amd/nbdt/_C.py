@@ -62,6 +62,7 @@ SIGNATURES = {
     "nbdt_set_deterministic": (c_int, [c_int32]),
     "nbdt_get_deterministic": (c_int, []),
     "nbdt_set_reserved_cus": (c_int, [c_int32]),
+    "nbdt_probe_mfma_stream": (c_int, [c_int32, c_int32, _P, _P]),
     "nbdt_get_reserved_cus": (c_int, []),
     "nbdt_tree_create": (c_int, [c_int, c_int, c_int, c_int, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P,
                                  POINTER(c_void_p)]),

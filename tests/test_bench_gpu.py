@@ -28,6 +28,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["achieved"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+    # measured ceilings beside the spec peak: the dominant kernel's own steady-state K loop and a
+    # register-only MFMA stream, both on this box, after the timed loop
+    assert r["attainable_kernel"] == "conv3x3_pp_kernel" and 0 < r["attainable"] <= r["mfma_stream"] * 1.02 < 1.02 * r["peak"]
+    assert abs(r["frac_of_attainable"] - r["achieved"] / r["attainable"]) < 1e-3
+    assert 0.3 < r["attainable_frac_of_peak"] < 1 and 0.5 < r["mfma_stream_frac_of_peak"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]

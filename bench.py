@@ -90,8 +90,8 @@ def attainable(dev):
                     8-wave kernels), per-lane / per-instruction varying operands (csrc/probe.hip): no memory at all --
                     what is missing to 2.5 PF here is power / clock, nothing a schedule can recover;
       attainable    the dominant kernel's OWN K loop in steady state: conv3x3_pp_kernel<5,false,0,8> -- the kernel of the
-                    plain data gradients -- on a synthetic 3x3 conv with 5120 input channels (160 K chunks x 9 taps = 1440
-                    K steps per 512-pixel tile instead of 45; 256 tiles, one per CU): per K step exactly the production
+                    plain data gradients -- on a synthetic 3x3 conv with 2560 input channels (80 K chunks x 9 taps = 720
+                    K steps per 512-pixel tile instead of 45-180; 256 tiles, one per CU, operands cache-resident): per K step exactly the production
                     mix (20 MFMA 32x32x16, 14 ds_read_b128, the step's LDS-DMA pieces, the two barriers, the address
                     arithmetic in the MFMA shadow) with exactly the real dependencies, prologue + epilogue < 4 % of the
                     launch.  mfma_stream - attainable = what the loop's own schedule + its memory instructions cost;
@@ -115,7 +115,10 @@ def attainable(dev):
     blocks, iters = 256, 6000
     t = timed(lambda: check(lib().nbdt_probe_mfma_stream(blocks, iters, ptr(sink), stream_ptr(dev))), 3)
     stream_tf = blocks * 8 * iters * 16 * 32768.0 / t / 1e12
-    B, H, cin, cout = 128, 32, 5120, 160
+    # 16 images x 32x32, 2560 -> 1280 channels: 32 pixel tiles x 8 cout tiles = 256 items (one per CU), 80 K chunks x 9
+    # taps = 720 K steps per tile (production: 45-180); input 95 MB + weights 59 MB stay in the 256 MB Infinity Cache /
+    # the L2s like production's operands do (a 1.5 GB input made every halo piece an exposed HBM round trip: 1248 TF/s)
+    B, H, cin, cout = 16, 32, 2560, 1280
     x = ops.padded(B, H, H, cin, dev)
     ops.interior(x).normal_()
     wb = (torch.randn(cout, 9, cin, device=dev) * 0.02).to(torch.bfloat16)
@@ -130,8 +133,8 @@ def attainable(dev):
     del x, wb, wt, out
     return {"mfma_stream": round(stream_tf, 1), "attainable": round(loop_tf, 1), "attainable_kernel": kernel,
             "attainable_how": "steady-state K loop of the dominant kernel: the same conv3x3_pp_kernel<5,false,0,8> on a "
-                              "synthetic 128x32x32 conv with 5120 input channels (1440 K steps per tile, 256 tiles, one "
-                              "per CU; 1.93 PFLOP per launch), HIP events over 3 launches after the timed loop; "
+                              "synthetic 16x32x32 conv, 2560 -> 1280 channels (720 K steps per tile, 32 x 8 = 256 tiles, "
+                              "one per CU, operands resident in the Infinity Cache; 0.97 PFLOP per launch), HIP events over 3 launches after the timed loop; "
                               "mfma_stream = register-only 32x32x16 bf16 MFMA stream on 256 CUs x 8 waves "
                               "(nbdt_probe_mfma_stream): the power / clock ceiling"}
 
@@ -482,6 +485,7 @@ def main():
                     out["roofline"]["frac_of_attainable"] = round(k["tflops"] / a["attainable"], 4)
                     out["roofline"]["attainable_frac_of_peak"] = round(a["attainable"] / PEAK_BF16_TFLOPS, 4)
                     out["roofline"]["mfma_stream_frac_of_peak"] = round(a["mfma_stream"] / PEAK_BF16_TFLOPS, 4)
+                    out["roofline"]["frac_of_mfma_stream"] = round(k["tflops"] / a["mfma_stream"], 4)
                 except Exception as exc:          # a probe must never cost the bench line
                     out["roofline"]["attainable"] = None
                     out["roofline"]["attainable_error"] = repr(exc)[:300]

@@ -23,6 +23,7 @@ using namespace nbdt;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 namespace nbdt {
 struct WgradTapsParams {
@@ -359,9 +360,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
   // 7.2 and 14.4 B/clk/CU against 52 for contiguous KiB) -- per 32-pixel stage that is 1850 cycles of address
   // processing for 765 cycles of MFMA: the 4-wave kernel's 42 % MFMA utilisation IS that ratio.  Pixel-major rows
   // make a gy piece 3.2 whole pixel rows (8-9 lines) and an x piece 16 pixels x 64 B (16 lines).
-  // ds_read_b64_tr_b16 gathers [4 px][16 ch] blocks with a free row stride, so it reads this image directly; the
-  // 32-byte block a 16-lane group reads is XOR-swapped with its neighbour for pixels with bit 2 set (on the DMA
-  // SOURCE address and on the read address), which keeps pixels p and p+4 of one 32-lane pass on different banks.
+  // ds_read_b64_tr_b16 gathers [4 px][16 ch] blocks with a free row stride, so it reads this image directly.
+  //
+  // K order (round 5).  Which pixel an MFMA k index stands for is free as long as both operands agree.  The 16-lane
+  // group g4 of a fragment holds k = 8 g4 .. 8 g4 + 7; rounds 2-4 gave it pixels {4 g4 .. +3, 16 + 4 g4 .. +3} of the
+  // 32-pixel chunk, now it has EIGHT CONSECUTIVE pixels 8 g4 .. 8 g4 + 7 of one image row (8 | cs).  Then the x operands
+  // of the three taps of a kernel row (r, 0..2) are the windows [c, c+8), [c+1, c+9), [c+2, c+10) of ONE 12-pixel run
+  // of halo row y + r: three transpose reads (pixels c..c+3, c+4..c+7, c+8..c+11) serve all three taps -- tap s = 0 and
+  // s = 2 are register sub-ranges, s = 1 is four v_perm -- where each tap used to read its own two blocks: 6 x-reads
+  // per K chunk and wave instead of 10 / 8 (16 reads per chunk with the 10 of gy, was 20 / 18).  A wave's 8-byte
+  // transpose reads complete one per ~38 cycles whatever surrounds them (s_memtime, profiles/r05_wgrad_segments.txt:
+  // 16 reads 610 cycles of a 970-cycle load segment), so reads per MFMA are a lever: load segment 1022 -> 972 cycles,
+  // MFMA segment of group 0 (reads of the second chunk in its shadow) 1053 -> 977, stage 2236 -> 2123.
+  // Bank swizzle: the two 16-lane groups of a 32-lane LDS pass read pixels 8 apart (or, for 8-wide images, one image row
+  // apart), i.e. the same 64-byte rows of the 256-byte bank line; the 32-byte half a group reads is XOR-swapped by a key
+  // that differs between the two -- gy: bit 3 of the pixel; x: (halo column >> 3) ^ halo row -- on the DMA source
+  // address and on the read address.
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   unsigned g_voff[IPG];                        // gy pieces {wave + 8k}: piece = LDS bytes [1024 id, +1024)
 #pragma unroll
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
     const int pos = (wave + 8 * k) * 1024 + lane * 16;
     int px = pos / PG;
     const int j = (pos - px * PG) >> 4;        // 16-byte chunk of the row this lane fills
-    const int src_chunk = j ^ (((px >> 2) & 1) << 1);
+    const int src_chunk = j ^ (((px >> 3) & 1) << 1);
     px = px < KSP ? px : KSP - 1;              // (ids past the tile are never issued)
     g_voff[k] = (unsigned)((px / cs) * g_hs + (px % cs) * g_ws + d.g_base + co0 + src_chunk * 8) * 2u;
   }
@@ -377,9 +391,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int slot = 16 * (wave + 8 * k) + (lane >> 2);
-    const int src_chunk = (lane & 3) ^ (((slot >> 2) & 1) << 1);
     const int hp = slot < hp_n ? slot : hp_n - 1;          // unused slots re-fetch the last halo pixel
-    x_voff[k] = (unsigned)((hp / hw2) * x_hs + (hp % hw2) * x_ws + d.x_base + ci0 + src_chunk * 8) * 2u;
+    const int hrow = hp / hw2, hcol = hp - hrow * hw2;
+    const int src_chunk = (lane & 3) ^ ((((hcol >> 3) ^ hrow) & 1) << 1);
+    x_voff[k] = (unsigned)(hrow * x_hs + hcol * x_ws + d.x_base + ci0 + src_chunk * 8) * 2u;
   }
   int n_mine = 1 + (wave + 8 < X_INSTR ? 1 : 0);           // DMA instructions this wave issues per stage
 #pragma unroll
@@ -413,28 +428,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
 #pragma unroll
     for (int a = 0; a < WM; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- transpose-read addressing: 16-lane group g4 reads pixels 4 g4 .. 4 g4+3 (and +16) of a 32-pixel K chunk,
-  // lane t16 the 8 bytes (4 channels) number t16&3 of pixel 4 g4 + (t16>>2) in a 16-channel block; it ends up with
-  // channel t16.
+  // ---- transpose-read addressing: 16-lane group g4 reads pixels 8 g4 .. 8 g4+3 (and +4) of a 32-pixel K chunk,
+  // lane t16 the 8 bytes (4 channels) number t16&3 of pixel 8 g4 + (t16>>2) in a 16-channel block; it ends up with
+  // channel t16 of the four pixels.
   typedef const __attribute__((address_space(3))) unsigned char* lds_cptr;
   typedef __attribute__((address_space(3))) s16x4* lds_tr;
   const lds_cptr smem3 = (lds_cptr)smem;
   const int g4 = lane >> 4, t16 = lane & 15;
-  const int rr = 4 * g4 + (t16 >> 2);
+  const int pr = t16 >> 2;                     // pixel of the 4-pixel block this lane addresses
   const int c8 = (t16 & 3) * 8;
-  // gy: 16-cout block b of pixel px sits at px*PG + (b ^ ((px>>2)&1))*32; (px>>2)&1 == g4&1 for px = rr + 16 j.
+  // gy: 16-cout block b of pixel px sits at px*PG + (b ^ ((px>>3)&1))*32; (px>>3)&1 == g4&1 for px = 32 kk + 8 g4 + j.
   // Blocks b and b+2 swap the same way: two per-lane bases (tiles a = 0, 1), the rest are +64 B immediates.
   int g_lane_off[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) g_lane_off[a] = rr * PG + (((wm * WM + a) ^ (g4 & 1)) * 32) + c8;
-  int xpos[KK][2];                             // halo slot of this lane's pixels 32 kk + rr (+16) at tap (0,0)
+  for (int a = 0; a < 2; ++a) g_lane_off[a] = (8 * g4 + pr) * PG + (((wm * WM + a) ^ (g4 & 1)) * 32) + c8;
+  // x: halo row / column (tap (0,0)) of pixel 32 kk + 8 g4 of the stage rectangle, the start of this group's run
+  int xrow0[KK], xcol0[KK];
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = kk * 32 + rr + 16 * h;
-      xpos[kk][h] = (k / cs) * hw2 + (k % cs);
-    }
+  for (int kk = 0; kk < KK; ++kk) {
+    const int k = kk * 32 + 8 * g4;
+    xrow0[kk] = k / cs;
+    xcol0[kk] = k - xrow0[kk] * cs;
+  }
   const int x_lane_off = G_BYTES + c8;
 
   // ---- prologue: stages 0 .. PD-1, all landed before the first load segment
@@ -453,20 +468,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
   // One group's main loop; T0 / NTP are literals so every register array is statically indexed.
   auto run = [&](auto t0_c, auto ntp_c) {
     constexpr int T0 = decltype(t0_c)::value, NTP = decltype(ntp_c)::value;
-    // x fragment offsets inside a stage slot: per lane, per (K chunk, tap, pixel half) -- stage independent, so
-    // they are computed once; a stage only adds its slot base (one v_add each, in the MFMA segment's shadow)
-    int xrel[KK][NTP][2];
+    // x fragment offsets inside a stage slot: per lane, per (K chunk, kernel row, 4-pixel block of the 12-pixel run) --
+    // stage independent, so they are computed once; a stage only adds its slot base (one v_add each, in the MFMA
+    // segment's shadow).  This group's taps T0 .. T0+NTP-1 lie in kernel rows R0 .. R0+NR-1.
+    constexpr int R0 = T0 / 3, NR = (T0 + NTP - 1) / 3 - R0 + 1;
+    int xrel[KK][NR][3];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-      for (int t = 0; t < NTP; ++t)
+      for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int toff = ((T0 + t) / 3) * hw2 + ((T0 + t) % 3);
-          const int hs = xpos[kk][h] + toff;               // halo slot; its 32-byte half: wn ^ bit 2 of the slot
-          xrel[kk][t][h] = x_lane_off + ((hs << 6) | ((((hs >> 2) ^ wn) & 1) << 5));
+        for (int q = 0; q < 3; ++q) {
+          const int hrow = xrow0[kk] + R0 + r, hcol = xcol0[kk] + 4 * q + pr;
+          const int hs = hrow * hw2 + hcol;                // halo slot; its 32-byte half: wn ^ key(row, column)
+          xrel[kk][r][q] = x_lane_off + ((hs << 6) | (((((hcol >> 3) ^ hrow) ^ wn) & 1) << 5));
         }
-    lds_cptr xa[KK][NTP][2];                   // x fragment addresses of the next load segment
+    lds_cptr xa[KK][NR][3];                    // x block addresses of the next load segment
     lds_cptr ga[2];
     auto prepare = [&](int slot_i) {
       int off = slot_i * STAGE;
@@ -477,10 +494,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-          xa[kk][t][0] = base + xrel[kk][t][0];
-          xa[kk][t][1] = base + xrel[kk][t][1];
-        }
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) xa[kk][r][q] = base + xrel[kk][r][q];
     };
     prepare(0);
     int slot_n = 1 % NSLOT, slot_d = PD % NSLOT;
@@ -493,28 +509,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
 #endif
     for (int u = 0; u < n_st; ++u) {
       // ================= L(u): fragments -> registers, this wave's DMA pieces of stage u + PD =================
-      bf16x8 gf[KK][WM], xf[KK][NTP];
+      bf16x8 gf[KK][WM];
+      u32x2 xw[KK][NR][3];                     // the 12-pixel runs: [block q] = pixels 4q .. 4q+3 of this lane's channel
       auto read_chunk = [&](auto kk_c) {
         constexpr int kk = decltype(kk_c)::value;
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
-#ifdef NBDT_WPP_GY_B128      // timing experiment: what a K-major gy image read with ds_read_b128 would cost (wrong results)
-          const int i16 = lane & 15, g16 = lane >> 4;
-          const lds_cptr a0 = ga[0] - g_lane_off[0] + ((kk * CG + (wm * WM + a) * 16 + i16) * 64 + ((g16 ^ ((i16 >> 1) & 3)) << 4));
-          gf[kk][a] = *(const __attribute__((address_space(3))) bf16x8*)a0;
-#else
           const lds_cptr a0 = ga[a & 1] + ((a >> 1) * 64 + kk * 32 * PG);
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 16 * PG));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * PG));
           gf[kk][a] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#endif
         }
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[kk][t][0]);
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[kk][t][1]);
-          xf[kk][t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            xw[kk][r][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[kk][r][q]));
+      };
+      // x operand of tap T0 + t for K chunk kk: pixels s .. s+7 of the run of kernel row (T0 + t) / 3
+      auto x_frag = [&](int kk, int t) {
+        const int r = (T0 + t) / 3 - R0, sft = (T0 + t) % 3;
+        const u32x2 A = xw[kk][r][0], B = xw[kk][r][1], C = xw[kk][r][2];
+        u32x4_t v;
+        if (sft == 0) v = u32x4_t{A[0], A[1], B[0], B[1]};
+        else if (sft == 2) v = u32x4_t{A[1], B[0], B[1], C[0]};
+        else v = u32x4_t{__builtin_amdgcn_alignbit(A[1], A[0], 16), __builtin_amdgcn_alignbit(B[0], A[1], 16),
+                         __builtin_amdgcn_alignbit(B[1], B[0], 16), __builtin_amdgcn_alignbit(C[0], B[1], 16)};
+        return __builtin_bit_cast(bf16x8, v);
       };
       // Only the FIRST K chunk's fragments are read here: 8-byte LDS reads reach their rate only with several waves
       // per SIMD in flight, and a load segment has one -- all 40 reads took ~870 cycles (s_memtime), longer than
@@ -567,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
         for (int t = 0; t < NTP; ++t)
 #pragma unroll
           for (int a = 0; a < WM; ++a)
-            acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kk][a], xf[kk][t], acc[t][a], 0, 0, 0);
+            acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kk][a], x_frag(kk, t), acc[t][a], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < KK * NTP * WM; ++i) {              // one MFMA, one of each other kind in its shadow
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) asm volatile("" : "+v"(xa[kk][t][0]), "+v"(xa[kk][t][1]));
+        for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(xa[kk][r][0]), "+v"(xa[kk][r][1]), "+v"(xa[kk][r][2]));
       asm volatile("" : "+v"(ga[0]), "+v"(ga[1]));
       __builtin_amdgcn_s_setprio(0);
       NBDT_WSTAMP(tm_m)
@@ -720,7 +741,8 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
 // the 8-wave kernel: 64-pixel stages must tile the images (halo <= 144 slots) and a block needs a few dozen of
 // them to amortise its prologue; the 32-bit lane offsets of its DMA need tensors below 4 GiB
 static bool pp_fits_shape(const nbdt_wgrad_desc* d) {
-  return stage_geometry(d, 64, 144, nullptr) && (long long)d->B * d->x_bs * 2 < (1ll << 32) &&
+  // (d->gw % 8: a fragment's 16-lane group holds 8 consecutive pixels of ONE image row)
+  return d->gw % 8 == 0 && stage_geometry(d, 64, 144, nullptr) && (long long)d->B * d->x_bs * 2 < (1ll << 32) &&
          (long long)d->B * d->g_bs * 2 < (1ll << 32);
 }
 static bool takes_pp(const nbdt_wgrad_desc* d, bool pp_fits) {

@@ -182,7 +182,9 @@ typedef struct nbdt_conv_desc {
   int32_t wide_tile;            /* dense 3x3 stride-1 launches: 0 / 1 = pick the kernel from the grid size (512-pixel
                                    ping-pong tiles when they give >= 3/4 of the CUs a block, else 256-pixel tiles);
                                    2 = force the 512-pixel kernel (error if the shape does not fit it), 3 = force the
-                                   256-pixel kernel.  2 / 3 exist for tests and A/B measurements. */
+                                   256-pixel kernel, 4 = force the 512-pixel kernel with its padded LDS pitch (images
+                                   narrower than 32 pixels: bank-conflict-free halo reads, measured 1-2 % slower, so
+                                   never picked automatically).  2 / 3 / 4 exist for tests and A/B measurements. */
   int32_t reserved;
   uint64_t w_tiled;             /* 0, or device pointer to the same weights pre-arranged by nbdt_weight_tile_batched
                                    (only dense 3x3 stride-1 launches with the identity tap map use it) */

@@ -18,7 +18,7 @@
 // product build is a compile error, not a silently wrong gradient.
 #if !defined(NBDT_TIMING_BUILD) &&                                                                                    \
     (defined(NBDT_WPP_NO_EPI) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
-     defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) ||                    \
+     defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) || defined(NBDT_PP_NO_PAD) ||                    \
      defined(NBDT_HALO_NO_ACCUMULATE) || defined(NBDT_DW_TARGET) || defined(NBDT_DW_U) || defined(NBDT_HEAD_SPB) ||    \
      defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) ||                       \
      (defined(NBDT_HEAD_SKIP) && (NBDT_HEAD_SKIP + 0) != 0) || (defined(NBDT_PP_ABLATE) && (NBDT_PP_ABLATE + 0) != 0) || \
@@ -192,6 +192,13 @@ struct HaloGeom {
   int a_bytes;         // a_instr * 1024
   int blocks_per_img;  // gh / rb when ib == 1
   int nwv;             // waves per block: 4 (256-pixel tile) or 8 (512-pixel tile)
+  // LDS image of the halo (conv3x3_pp_kernel): rows of `lpitch` pixel slots.  pad = lpitch - hw2 is 0 (the halo is copied
+  // as the one contiguous run it is in memory; a_instr covers hp pixels) or 2 for images narrower than 32 pixels: rows of
+  // gw + 4 slots, the last two of each row unused, so that a 32-pixel fragment -- 2 or 4 image rows -- meets every bank
+  // once (conv_halo.hip, "LDS pitch").  dv = lpitch - (row multiplier of the swizzle coordinate): 0 or 4.
+  int lpitch, limg;    // slots per halo row / per image ((rb+2) * lpitch)
+  int pad, dv;
+  int row_magic;       // ceil(65536 / lpitch): slot / lpitch == (slot * row_magic) >> 16 for slot < 2048
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
 extern thread_local const char* g_last_wgrad;   // ... and the last nbdt_conv_wgrad call
@@ -217,6 +224,17 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
       : "=&s"(keep)
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
+}
+
+// The same with every wave-uniform operand passed through v_readfirstlane first.  hipcc's instruction selection hands an
+// "s"-constrained asm operand a VGPR when its divergence analysis is not sure the value is uniform -- which happens as
+// soon as a vector expression of the same function shares a subterm with the scalar address arithmetic (round 4's
+// swizzle draft stopped there: "invalid operand for instruction: s_mov_b32 m0, v6").  A readfirstlane of a value that IS
+// in an SGPR folds away; one of a value the compiler moved to a VGPR is one VALU instruction and the 5 wait states the pad covers.
+__device__ __forceinline__ void glds16_sf(const void* sbase, unsigned voff, unsigned lds_dst) {
+  const unsigned long long b = (unsigned long long)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  glds16_s((const void*)(((unsigned long long)hi << 32) | lo), voff, __builtin_amdgcn_readfirstlane(lds_dst));
 }
 
 namespace nbdt {

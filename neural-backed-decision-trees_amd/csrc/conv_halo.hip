@@ -107,7 +107,22 @@ __device__ __forceinline__ unsigned stamp() {
 // the barrier that precedes the first reader (group 0, L(t+2)).  A(kc+1) overwrites the buffer of A(kc-1),
 // dead since step 9kc-1; its pieces are issued at taps 0..6 of slice kc and retired by the wait two steps later
 // (tap 6 -> the vmcnt(0) of tap 8), a barrier before step 9kc+9 reads them.  Nothing but vmcnt + a barrier orders LDS-DMA against ds_read.
-template <int NT, bool HAS_RES, int STATS, int NWV>
+//
+// LDS pitch (round 5, PAD = true; images narrower than 32 pixels).  A ds_read_b128 is served in passes of 16 lanes --
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same in the upper half -- and the 16-byte chunk swizzle
+// c ^ ((p >> 2) & 3) makes a pass conflict-free when its 16 pixels are DISTINCT MOD 16, which consecutive pixels of the
+// passes' lane sets are.  A 32-pixel fragment is one row of a 32-wide image but two rows of a 16-wide and four of an
+// 8-wide one, and in a halo copied as the contiguous run it is in memory the row pitch is W + 2: lanes 20-27 sit at
+// p + 22 .. p + 29, which collides with lanes 12-15 -- SQ_LDS_BANK_CONFLICT 24 % (16x16) and 37 % (8x8) of the LDS-active
+// cycles (profiles/r04_lds_conflicts_by_stage.txt).  With W + 2 = 2 (mod 4) no swizzle fixes that (the physical quarter
+// p & 3 flips between rows: DESIGN 5.3).  So the LDS image gets rows of W + 4 slots -- the DMA skips two slots per row;
+// what lands in them is never read -- and the swizzle is taken on the DE-PITCHED coordinate v = column + W * row: the
+// physical quarter is column & 3 in every row, a fragment's pixels are consecutive in v whatever the tap, and the
+// original argument holds again: zero conflicts at every width.  Costs: 11 % (16x16) / 20 % (8x8) more LDS for the two
+// halo buffers -- 8x8x8-image tiles need 60 pieces per slice where taps 0..6 give 56 issue slots: waves 0-3 issue a second
+// piece at tap 0 -- and ~8 VALU per K step in the MFMA segment's shadow (a slot's row by multiply-shift, packed (slot, v)
+// fragment coordinates).  PAD = false is the kernel of rounds 2-4, instruction for instruction (32-wide images).
+template <int NT, bool HAS_RES, int STATS, int NWV, bool PAD>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams p, nbdt::HaloGeom hg) {
   constexpr bool PP = NWV == 8;          // two wave groups alternating roles; NWV == 4: one group, two blocks per CU
   constexpr int APW = PP ? 1 : 2;        // halo pieces a wave may issue per step (taps 0..6: 7 * NWV * APW slots)
@@ -147,6 +162,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   const int a_bytes = NBDT_PIN(hg.a_bytes);
   const int a_instr = NBDT_PIN(hg.a_instr);
   const int hw2 = NBDT_PIN(hg.hw2), himg = NBDT_PIN(hg.himg);
+  const int lpitch = NBDT_PIN(hg.lpitch), limg = NBDT_PIN(hg.limg), row_magic = NBDT_PIN(hg.row_magic);   // (PAD only)
   const unsigned long long in_u = (unsigned long long)p.in, w_u = (unsigned long long)p.w_tiled;
   const bf16_t* in_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(in_u >> 32)) << 32) |
                                           (unsigned)NBDT_PIN((unsigned)in_u));
@@ -177,14 +193,28 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   // which holds source chunk (lane&3) ^ swizzle(pixel); 16 | 16*id so the swizzle (pixel>>2)&3 is per lane.
   // (the per-lane constants below are recomputed at the top of every tile from an opaque copy of `lane`: kept
   // live across the epilogue they cost the accumulator pass registers it does not have)
-  int a_lane_pix, a_lane_el;
+  int a_lane_pix, a_lane_el;                          // (PAD: a_lane_el holds the chunk POSITION lane & 3)
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // PAD: byte offset of what LDS slot x = 16 id + (lane >> 2), chunk position lane & 3, must hold.  Slot x is column
+  // x - R * lpitch of halo row R = x / lpitch (rows of all the tile's images, stacked); the halo in memory has rows of
+  // lpitch - 2 pixels, so its pixel is base + x - 2 R, and the chunk is the position XOR the swizzle of v = x - 4 R.
+  auto pad_voff = [&](int x, int lc, int pix_base) {
+    const int R = (x * row_magic) >> 16;
+    int px = x - 2 * R + pix_base;
+    px = px < last_pix ? px : last_pix;                // tail lanes / images past the batch re-read the last pixel
+    const int v = x - 4 * R;
+    return (unsigned)(px * cin + ((lc ^ ((v >> 2) & 3)) << 3)) * 2u;
+  };
   auto issue_a_piece = [&](int base_pix, int buf, int kc, int id) {
-    int lp = a_lane_pix;
-    asm volatile("" : "+v"(lp));                      // keep this address math inside the step (registers)
+    int lp = a_lane_pix, le = a_lane_el;
+    asm volatile("" : "+v"(lp), "+v"(le));            // keep this address math inside the step (registers)
+    if (PAD) {
+      glds16_sf(in_base + kc * BK, pad_voff(lp + id * 16, le, base_pix), lds_base + buf * a_bytes + id * 1024);
+      return;
+    }
     int px = lp + (base_pix + id * 16);
     px = px < last_pix ? px : last_pix;                // tail lanes / images past the batch re-read the last pixel
-    glds16_s(in_base + kc * BK, (unsigned)(px * cin + a_lane_el) * 2u, lds_base + buf * a_bytes + id * 1024);
+    glds16_s(in_base + kc * BK, (unsigned)(px * cin + le) * 2u, lds_base + buf * a_bytes + id * 1024);
   };
   // W piece `id` = rows [16 id, 16 id + 16) of a weight tile.  The weights are the DMA-ordered tiles of
   // nbdt_weight_tile_batched: tile (n_blk, kc, tap) IS the swizzled LDS image, stored contiguously in step order,
@@ -215,7 +245,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     int ln = lane;
     asm volatile("" : "+v"(ln));
     a_lane_pix = ln >> 2;
-    a_lane_el = (((ln & 3) ^ ((ln >> 4) & 3)) << 3);
+    a_lane_el = PAD ? (ln & 3) : (((ln & 3) ^ ((ln >> 4) & 3)) << 3);
     w_voff = ln * 16u;
     const int frag_row = ln & 31;
     frag_half = ln >> 5;
@@ -226,7 +256,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
       const int img = pl / per_img;
       const int rem = pl - img * per_img;
       const int r = rem / d.gw, c = rem - r * d.gw;
-      hp0[tm] = img * himg + r * hw2 + c;
+      // PAD: LDS slot | swizzle coordinate << 16 (both < 2048: 8 x 10 x 12 = 960 slots at most)
+      hp0[tm] = PAD ? ((img * limg + r * lpitch + c) | ((img * limg + r * lpitch + c - 4 * (img * (hg.rb + 2) + r)) << 16))
+                    : img * himg + r * hw2 + c;
     }
     const int w_frag_off = frag_row * 64 + ((frag_half ^ ((frag_row >> 2) & 3)) << 4);   // ks = 0; ks = 1 is ^ 32
     w_rd0 = 2 * a_bytes + w_frag_off;
@@ -244,22 +276,29 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     lds_cptr ra[2][2];        // LDS addresses of the pixel fragments [ks][tm]
     unsigned a_voff[APW];     // halo pieces: per-lane byte offsets
     int a_n;                  // ... and how many of them this wave issues in L(t)
+    unsigned a_xoff;          // PAD: piece 56 + wave of the next slice, issued at tap 0 when the slice has more than
+    int a_x;                  //      the 56 pieces taps 0..6 have slots for (8x8 images: 60)
   };
   int a_pix0 = cur.base_pix + wave * 16;       // halo pixel of lane 0 of this wave's piece at tap 0 (per tile)
   auto prepare = [&](int tapn, int kcn) {     // plan of L(t) for t = (kcn, tapn); tapn is a literal after unrolling
     Plan q;
-    int h0 = hp0[0], h1 = hp0[1], lp = a_lane_pix;
-    asm volatile("" : "+v"(h0), "+v"(h1), "+v"(lp));    // the address math stays in the segment that calls prepare()
-    const int toff = (tapn / 3) * hw2 + (tapn % 3);
+    int h0 = hp0[0], h1 = hp0[1], lp = a_lane_pix, le = a_lane_el;
+    asm volatile("" : "+v"(h0), "+v"(h1), "+v"(lp), "+v"(le));    // the address math stays in the segment that calls prepare()
+    // tap offset: halo pixels; PAD: LDS slots | de-pitched pixels << 16 (rows of lpitch slots / lpitch - 4 pixels)
+    const int toff = PAD ? (((tapn / 3) * lpitch + (tapn % 3)) | (((tapn / 3) * (lpitch - 4) + (tapn % 3)) << 16))
+                         : (tapn / 3) * hw2 + (tapn % 3);
     const unsigned abuf = (kcn & 1) * a_bytes;
+    auto frag_off = [&](int h) {
+      const int hp = h + toff;
+      if (PAD) return (unsigned)(((hp << 6) & 0x3fffc0) + ((frag_half ^ ((hp >> 18) & 3)) << 4));
+      return (unsigned)(hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4));
+    };
     {
-      const int hp = h0 + toff;
-      const unsigned o = hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4);
+      const unsigned o = frag_off(h0);
       q.ra[0][0] = smem3 + (abuf + o); q.ra[1][0] = smem3 + (abuf + (o ^ 32));
     }
     {
-      const int hp = h1 + toff;
-      const unsigned o = hp * 64 + ((frag_half ^ ((hp >> 2) & 3)) << 4);
+      const unsigned o = frag_off(h1);
       q.ra[0][1] = smem3 + (abuf + o); q.ra[1][1] = smem3 + (abuf + (o ^ 32));
     }
     // up to APW pieces of the next halo slice per wave at taps 0..6: piece id = (tapn * APW + j) * NWV + wave
@@ -268,9 +307,19 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     for (int j = 0; j < APW; ++j) {
       const int id0 = (tapn * APW + j) * NWV;            // literal
       if (tapn < 7 && kcn + 1 < kchunks && id0 + wave < a_instr) q.a_n = j + 1;
+      if (PAD) {
+        q.a_voff[j] = pad_voff(lp + (id0 + wave) * 16, le, a_pix0 - wave * 16);
+        continue;
+      }
       int px = lp + (a_pix0 + id0 * 16);
       px = px < last_pix ? px : last_pix;     // tail lanes / images past the batch re-read the last pixel
-      q.a_voff[j] = (unsigned)(px * cin + a_lane_el) * 2u;
+      q.a_voff[j] = (unsigned)(px * cin + le) * 2u;
+    }
+    q.a_x = 0;
+    q.a_xoff = 0;
+    if (PAD && tapn == 0) {
+      q.a_x = (kcn + 1 < kchunks && 7 * APW * NWV + wave < a_instr) ? 1 : 0;
+      q.a_xoff = pad_voff(lp + (7 * APW * NWV + wave) * 16, le, a_pix0 - wave * 16);
     }
     return q;
   };
@@ -279,7 +328,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   auto issue_first = [&](const Tile& t) {
     if (abl & 1) return;
 #pragma unroll
-    for (int k = 0; k < 7 * APW; ++k)
+    for (int k = 0; k < (PAD ? 8 : 7) * APW; ++k)
       if (wave + NWV * k < a_instr) issue_a_piece(t.base_pix, 0, 0, wave + NWV * k);
     issue_w(t.w_tiles, 0, 0);
     issue_w(t.w_tiles, 1, 1);
@@ -372,9 +421,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
             if (j < plan.a_n)
               glds16_s(in_base + (kc + 1) * BK, plan.a_voff[j],
                        lds_base + ((kc + 1) & 1) * a_bytes + ((tap * APW + j) * NWV + wave) * 1024);
+          if (PAD && tap == 0 && plan.a_x)
+            glds16_sf(in_base + (kc + 1) * BK, plan.a_xoff,
+                      lds_base + ((kc + 1) & 1) * a_bytes + (7 * APW * NWV + wave) * 1024);
         }
       }
-      prev_a = (abl & 3) ? 0 : plan.a_n;
+      prev_a = (abl & 3) ? 0 : plan.a_n + ((PAD && tap == 0) ? plan.a_x : 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       NBDT_STAMP(tm_l)
       __builtin_amdgcn_sched_barrier(0);
@@ -421,6 +473,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
       }
       asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[0][1]), "+v"(plan.ra[1][0]), "+v"(plan.ra[1][1]), "+v"(plan.a_voff[0]));
       if (APW == 2) asm volatile("" : "+v"(plan.a_voff[APW - 1]));
+      if (PAD && tap == 8) asm volatile("" : "+v"(plan.a_xoff));
       if (!(NBDT_PP_SCHED & 1)) __builtin_amdgcn_s_setprio(0);
       NBDT_STAMP(tm_m)
       __builtin_amdgcn_sched_barrier(0);
@@ -659,7 +712,7 @@ thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): whic
 
 // KIND 0: conv3x3_pp_kernel<.., 8> (ping-pong), 1: conv3x3_pp_kernel<.., 4> (same segments, one group, two blocks
 // per CU), 2: conv3x3_halo_kernel (4 waves, plain weight layout)
-template <int NT, int KIND>
+template <int NT, int KIND, bool PAD>
 static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   constexpr int NWV = KIND == 0 ? 8 : 4;
   constexpr int BN = 32 * NT;
@@ -693,11 +746,11 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
     p.overlap = 0;
 #endif
   }
-  static DeviceAttr site;     // one per (NT, KIND) instantiation; re-raised when a launch needs more LDS
+  static DeviceAttr site;     // one per (NT, KIND, PAD) instantiation; re-raised when a launch needs more LDS
   const dim3 grid(per_round * 8), blk(64 * NWV);
 #define NBDT_KERNEL(R, S) \
   (KIND == 2 ? reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>) \
-             : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV>))
+             : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV, PAD>))
   if (site.need(shmem)) {
 #define NBDT_ATTR(R, S) \
   NBDT_ATTR_CHECK(site, hipFuncSetAttribute(NBDT_KERNEL(R, S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
@@ -714,7 +767,8 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   else { if (p.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
 #undef NBDT_GO
 #undef NBDT_KERNEL
-  g_last_igemm = KIND == 0 ? "conv3x3_pp_kernel" : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
+  g_last_igemm = KIND == 0 ? (PAD ? "conv3x3_pp_kernel/pad" : "conv3x3_pp_kernel")
+                           : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
   return NBDT_OK;
 }
 
@@ -724,8 +778,8 @@ static int cout_tile(int cout) {
 }
 
 // Fills hg when the pixel tiles of `tile` pixels are whole image rows / whole images and the two halo buffers
-// fit in LDS next to the weight ring.
-static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, HaloGeom* hg) {
+// fit in LDS next to the weight ring.  pad: the LDS image gets rows of gw + 4 slots (conv3x3_pp_kernel<.., PAD = true>).
+static bool halo_geom_try(const nbdt_conv_desc* d, int tile, int nwv, bool pad, HaloGeom* hg) {
   const int gw = d->gw, gh = d->gh;
   if (gw > tile || tile % gw != 0) return false;
   int ib, rb;
@@ -742,10 +796,17 @@ static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, HaloGeom* 
   hg->hw2 = gw + 2;
   hg->himg = (rb + 2) * (gw + 2);
   hg->hp = ib * hg->himg;
-  const int instr = (hg->hp * 4 + 63) / 64;
-  // pieces per wave: the 4-wave kernel keeps up to 10 in flight per slice, the ping-pong kernel issues one per
-  // wave per step at taps 0..6 (7 x 8 = 56 pieces)
-  if ((instr + nwv - 1) / nwv > (nwv == 4 ? 10 : 7) || instr < nwv) return false;
+  hg->pad = pad ? 2 : 0;
+  hg->dv = pad ? 4 : 0;
+  hg->lpitch = hg->hw2 + hg->pad;
+  hg->limg = (rb + 2) * hg->lpitch;
+  hg->row_magic = (65536 + hg->lpitch - 1) / hg->lpitch;
+  const int instr = (ib * hg->limg * 4 + 63) / 64;
+  // pieces per wave: the 4-wave kernels keep up to 10 in flight per slice (conv3x3_halo_kernel) / have 2 x 7 issue slots
+  // (conv3x3_pp_kernel<.., 4>); the ping-pong kernel issues one per wave per step at taps 0..6 (7 x 8 = 56 pieces), and
+  // its padded form a second one for waves 0-7 at tap 0 (64)
+  if (instr < nwv) return false;
+  if ((instr + nwv - 1) / nwv > (nwv == 4 ? 10 : (pad ? 8 : 7))) return false;
   hg->a_instr = instr;
   hg->a_bytes = instr * 1024;
   hg->blocks_per_img = ib == 1 ? gh / rb : 1;
@@ -753,10 +814,20 @@ static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, HaloGeom* 
   const int lds = 2 * hg->a_bytes + 3 * cout_tile(d->cout) * 32 * BK * 2;
   return lds <= (nwv == 4 ? 80 : 156) * 1024;   // 4 waves: 2 blocks per CU (80 KiB each); 8 waves: 1 block per CU
 }
+// pad: the caller asked for the padded LDS pitch (desc.wide_tile = 4; 8-wave kernel, images narrower than 32 pixels).
+// It is NOT what a launch gets by default: measured on MI355X (profiles/r05_lds_pitch_ab.txt) the padded kernel has no
+// bank conflicts left and is 1-2 % SLOWER than the contiguous image (16x16x320: 171 vs 169 us, 8x8x640: 164 vs 161) --
+// the conflicts sat in the load segment's slack under the partner's MFMA segment, while the extra address arithmetic of
+// the padded form sits in the MFMA segment's shadow, which has none.
+static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, bool pad, HaloGeom* hg) {
+  if (pad) return nwv == 8 && d->gw < 32 && d->gw % 4 == 0 && halo_geom_try(d, tile, nwv, true, hg);
+  return halo_geom_try(d, tile, nwv, false, hg);
+}
 
 // Dense 3x3 / stride-1 conv over a padded NHWC tensor?  Picks the 512-pixel ping-pong kernel when its grid gives
 // at least 3/4 of the 256 CUs a block (every WRN-28-10 layer at 512 images per GPU), else the 256-pixel kernel.
-// desc.wide_tile: 0/1 automatic, 2 force the 512-pixel kernel, 3 force the 256-pixel one (tests, A/B).
+// desc.wide_tile: 0/1 automatic, 2 force the 512-pixel kernel, 3 force the 256-pixel one, 4 force the 512-pixel kernel
+// with the padded LDS pitch (tests, A/B).
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
 #ifdef NBDT_HALO_NO_ACCUMULATE          // A/B builds: accumulating data gradients on the first-generation kernel (rounds 1-3)
   if (d->accumulate) return false;
@@ -774,10 +845,14 @@ bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
   bool tiled = d->w_tiled != 0 && d->w_ntaps == 9;
   for (int t = 0; t < 9; ++t) tiled = tiled && d->w_tap[t] == t;
   const long long tiles512 = ((long long)M + 511) / 512 * (d->cout / (32 * cout_tile(d->cout)));
+  if (d->wide_tile == 4) return tiled && halo_geom_for(d, 512, 8, true, hg);     // padded LDS pitch or an error
   const bool want_wide = tiled && (d->wide_tile == 2 || (d->wide_tile != 3 && tiles512 >= 192));
-  if (want_wide && halo_geom_for(d, 512, 8, hg)) return true;
+  if (want_wide && halo_geom_for(d, 512, 8, false, hg)) return true;
   if (d->wide_tile == 2) return false;
-  return halo_geom_for(d, 256, 4, hg);
+  // (the 4-wave form keeps the contiguous halo image at every width: its two pieces per wave and step with the padded
+  //  addressing do not get through hipcc -- "s"-constrained asm operands come out as VGPRs -- and it only serves grids
+  //  too small for 512-pixel tiles)
+  return halo_geom_for(d, 256, 4, false, hg);
 }
 
 int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, const void* w, void* out,
@@ -803,16 +878,19 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   p.M = M;
   p.deterministic = deterministic() ? 1 : 0;
   const int nt = cout_tile(d->cout);
-#define NBDT_DISPATCH(KIND)                                     \
-  {                                                             \
-    if (nt == 5) return launch_halo<5, KIND>(p, hg, st);        \
-    if (nt == 4) return launch_halo<4, KIND>(p, hg, st);        \
-    if (nt == 2) return launch_halo<2, KIND>(p, hg, st);        \
-    return launch_halo<1, KIND>(p, hg, st);                     \
+#define NBDT_DISPATCH(KIND, PAD)                                     \
+  {                                                                  \
+    if (nt == 5) return launch_halo<5, KIND, PAD>(p, hg, st);        \
+    if (nt == 4) return launch_halo<4, KIND, PAD>(p, hg, st);        \
+    if (nt == 2) return launch_halo<2, KIND, PAD>(p, hg, st);        \
+    return launch_halo<1, KIND, PAD>(p, hg, st);                     \
   }
-  if (hg.nwv == 8) NBDT_DISPATCH(0)
-  if (p.w_tiled != nullptr) NBDT_DISPATCH(1)
-  NBDT_DISPATCH(2)
+  // (a padded LDS pitch is only ever chosen together with DMA-ordered weights, i.e. for conv3x3_pp_kernel)
+  if (hg.pad != 0 && p.w_tiled == nullptr) return nbdt::fail(NBDT_EINVAL, "%s%s", "padded halo pitch without tiled weights", "");
+  if (hg.pad != 0 && hg.nwv != 8) return nbdt::fail(NBDT_EINVAL, "%s%s", "padded halo pitch is the 8-wave kernel's", "");
+  if (hg.nwv == 8) { if (hg.pad) NBDT_DISPATCH(0, true) else NBDT_DISPATCH(0, false) }
+  if (p.w_tiled != nullptr) NBDT_DISPATCH(1, false)
+  NBDT_DISPATCH(2, false)
 #undef NBDT_DISPATCH
 }
 

@@ -665,6 +665,20 @@ def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout):
     _close_bf16(ops.interior(out_pp), ref, "pp fwd")
     assert torch.equal(out_pp, out_h)
     _check_border_zero(out_pp)
+    # wide_tile = 4: the same kernel with the padded LDS pitch (rows of W + 4 slots, swizzle on the de-pitched coordinate;
+    # conflict-free halo reads for images narrower than 32 pixels) -- bit for bit the same output, plain and with the
+    # residual + statistics epilogue; a 32-wide image has no padded form
+    out_pad = ops.padded(B, H, W, cout, DEV)
+    if W < 32:
+        ops.conv_igemm(desc(4), xp, wb, out_pad)
+        assert ops.last_igemm_kernel() == "conv3x3_pp_kernel/pad" and torch.equal(out_pad, out_pp)
+        part_pad = torch.full((((B * H * W + 255) // 256) * 2 * cout,), float("nan"), device=DEV)
+        ops.conv_igemm(desc(4), xp, wb, out_pad, residual=rp, bn_scratch=part_pad)
+        ops.conv_igemm(desc(2), xp, wb, out_pp, residual=rp)
+        assert torch.equal(out_pad, out_pp) and torch.isfinite(part_pad).all()
+    else:
+        with pytest.raises(Exception, match="wide_tile"):
+            ops.conv_igemm(desc(4), xp, wb, out_pad)
     # residual + fused BatchNorm statistics epilogue
     n_part = ((B * H * W + 255) // 256) * 2 * cout
     part_pp = torch.full((n_part,), float("nan"), device=DEV)

@@ -431,6 +431,28 @@ int nbdt_ref_stem_conv(const float* img, const float* w, int32_t B, int32_t H, i
                        int32_t cpad, int32_t stride, float* out, void* stream);
 int nbdt_ref_stem_wgrad(const float* img, const float* gy, int32_t B, int32_t H, int32_t W, int32_t cout_real,
                         int32_t cpad, int32_t stride, float* dw, void* stream);
+/* fp32-storage twins of the MBConv pieces (EfficientNet-B0; verification only, like everything in this block): same
+ * arguments and meaning as nbdt_bn_act_apply / _pool / _bwd and nbdt_dwconv_fwd / _bwd_data / _bwd_weight.  The fused
+ * forms of the product path have no twin: a depthwise forward leaves no statistics (nbdt_ref_bn_stats re-reads the
+ * tensor), and the data gradient with BatchNorm-backward sums is nbdt_ref_dwconv_bwd_data followed by the full
+ * nbdt_ref_bn_act_bwd.  Replaces, for verification, pytorchcv dwconv / BatchNorm2d + Swish / SEBlock scaling behind
+ * nbdt/models/__init__.py:3. */
+int nbdt_ref_bn_act_apply(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                          const float* beta, int32_t act, const float* gate, const float* residual, int32_t B, int32_t H,
+                          int32_t W, int32_t C, float* y, void* stream);
+int nbdt_ref_bn_act_pool(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                         const float* beta, int32_t act, const float* mul, float scale, int32_t B, int32_t H, int32_t W,
+                         int32_t C, float* out, void* stream);
+int nbdt_ref_bn_act_bwd(const float* gu, const float* gate, const float* gpool, const float* x, const float* save_mean,
+                        const float* save_rstd, const float* gamma, const float* beta, int32_t act, const float* gx_add,
+                        int32_t B, int32_t H, int32_t W, int32_t C, float* dsum, float* dgamma, float* dbeta, float* gx,
+                        void* stream);
+int nbdt_ref_dwconv_fwd(const float* x, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                        int32_t stride, float* y, void* stream);
+int nbdt_ref_dwconv_bwd_data(const float* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                             int32_t stride, float* gx, void* stream);
+int nbdt_ref_dwconv_bwd_weight(const float* x, const float* gy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                               int32_t stride, float* dw, void* stream);
 
 /* ------------------------------------------------------------------ stem / head / optimizer */
 /* stem Conv2d(3->cout_real, 3x3, pad 1, stride 1|2) on NCHW fp32 images [B,3,H,W] -> padded NHWC

@@ -344,3 +344,264 @@ extern "C" int nbdt_ref_stem_wgrad(const float* img, const float* gy, int32_t B,
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// MBConv pieces (EfficientNet-B0, csrc/effnet.hip) in fp32 storage: BatchNorm + activation (+ SE gate, + skip), the
+// pooled sums, their backward, and the depthwise convolution with its two gradients.  Same arguments and meaning as the
+// product entry points (include/nbdt_hip.h "MBConv pieces"); the squeeze-and-excitation gate, dropout and the linear
+// head work on fp32 vectors in the product path already and have no twin here.
+__device__ __forceinline__ float ref_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float ref_act(float v, int act) {
+  if (act == NBDT_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == NBDT_ACT_SWISH) return v * ref_sigmoid(v);
+  return v;
+}
+__device__ __forceinline__ float ref_act_grad(float v, int act) {
+  if (act == NBDT_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (act == NBDT_ACT_SWISH) { const float s = ref_sigmoid(v); return s * (1.f + v * (1.f - s)); }
+  return 1.f;
+}
+
+// y = act(bn(x)) [* gate[b][c]] [+ residual]
+__global__ __launch_bounds__(256) void ref_bn_act_apply_kernel(const float* __restrict__ x, const float* mean,
+                                                               const float* rstd, const float* gamma, const float* beta,
+                                                               int act, const float* __restrict__ gate,
+                                                               const float* __restrict__ res, PadGeom g,
+                                                               float* __restrict__ y) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.npix * g.C) return;
+  const int c = (int)(idx % g.C), p = (int)(idx / g.C);
+  const int o = pad_offset(g, p) + c, b = p / (g.H * g.W);
+  const float sc = gamma[c] * rstd[c];
+  float v = ref_act(x[o] * sc + (beta[c] - mean[c] * sc), act);
+  if (gate) v *= gate[(size_t)b * g.C + c];
+  if (res) v += res[o];
+  y[o] = v;
+}
+
+// out[b][c] = scale * sum_hw act(bn(x)) [* mul]
+__global__ __launch_bounds__(256) void ref_bn_act_pool_kernel(const float* __restrict__ x, const float* mean,
+                                                              const float* rstd, const float* gamma, const float* beta,
+                                                              int act, const float* __restrict__ mul, float scale,
+                                                              PadGeom g, float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.B * g.C) return;
+  const int c = idx % g.C, b = idx / g.C, hw = g.H * g.W;
+  const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
+  double s = 0.0;
+  for (int p = 0; p < hw; ++p) {
+    const int o = pad_offset(g, b * hw + p) + c;
+    float v = ref_act(x[o] * sc + sh, act);
+    if (mul) v *= mul[o];
+    s += v;
+  }
+  out[(size_t)b * g.C + c] = (float)(s * (double)scale);
+}
+
+// gradient entering the activation of element o of image b, channel c (include/nbdt_hip.h, nbdt_bn_act_bwd)
+__device__ __forceinline__ float ref_act_in_grad(const float* gu, const float* gate, const float* gpool, int o, int b,
+                                                 int c, int C, int hw) {
+  if (!gu) return gpool[(size_t)b * C + c] / (float)hw;
+  float ga = gu[o];
+  if (gate) ga = ga * gate[(size_t)b * C + c] + gpool[(size_t)b * C + c] / (float)hw;
+  return ga;
+}
+
+__global__ __launch_bounds__(256) void ref_bn_act_bwd_sums_kernel(const float* __restrict__ gu, const float* gate,
+                                                                  const float* gpool, const float* __restrict__ x,
+                                                                  const float* mean, const float* rstd,
+                                                                  const float* gamma, const float* beta, int act,
+                                                                  PadGeom g, float* dsum, float* dgamma, float* dbeta) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x, hw = g.H * g.W;
+  const float mu = mean[c], rs = rstd[c];
+  const float sc = gamma[c] * rs, sh = beta[c] - mu * sc;
+  double s0 = 0.0, s1 = 0.0;
+  for (int p = threadIdx.x; p < g.npix; p += 256) {
+    const int o = pad_offset(g, p) + c;
+    const float xv = x[o];
+    const float gg = ref_act_in_grad(gu, gate, gpool, o, p / hw, c, g.C, hw) * ref_act_grad(xv * sc + sh, act);
+    s0 += gg; s1 += (double)gg * (double)((xv - mu) * rs);
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    dsum[c] = (float)red[0][0]; dsum[g.C + c] = (float)red[1][0];
+    if (dbeta) dbeta[c] += (float)red[0][0];
+    if (dgamma) dgamma[c] += (float)red[1][0];
+  }
+}
+
+// (gx may be gu: every element is read and written by the one thread that owns it)
+__global__ __launch_bounds__(256) void ref_bn_act_bwd_apply_kernel(const float* gu, const float* gate, const float* gpool,
+                                                                   const float* __restrict__ x, const float* mean,
+                                                                   const float* rstd, const float* gamma,
+                                                                   const float* beta, int act, const float* dsum,
+                                                                   const float* gx_add, PadGeom g, float* gx) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.npix * g.C) return;
+  const int c = (int)(idx % g.C), p = (int)(idx / g.C), hw = g.H * g.W;
+  const int o = pad_offset(g, p) + c;
+  const float mu = mean[c], rs = rstd[c];
+  const float sc = gamma[c] * rs, sh = beta[c] - mu * sc;
+  const float inv_n = 1.f / (float)g.npix;
+  const float xv = x[o];
+  const float gg = ref_act_in_grad(gu, gate, gpool, o, p / hw, c, g.C, hw) * ref_act_grad(xv * sc + sh, act);
+  float v = sc * (gg - dsum[c] * inv_n - (xv - mu) * rs * dsum[g.C + c] * inv_n);
+  if (gx_add) v += gx_add[o];
+  gx[o] = v;
+}
+
+// depthwise Conv2d(C, C, k, stride, padding k/2, groups = C); w [k*k][C]; x [B][H+2][W+2][C] -> y [B][H/s+2][W/s+2][C]
+__global__ __launch_bounds__(256) void ref_dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int B,
+                                                         int H, int W, int C, int k, int stride, float* __restrict__ y) {
+  const int Ho = H / stride, Wo = W / stride, pad = k / 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * Ho * Wo * C) return;
+  const int c = (int)(idx % C);
+  const int p = (int)(idx / C);
+  const int wo = p % Wo, ho = (p / Wo) % Ho, b = p / (Wo * Ho);
+  float acc = 0.f;
+  for (int r = 0; r < k; ++r)
+    for (int s = 0; s < k; ++s) {
+      const int hi = ho * stride + r - pad, wi = wo * stride + s - pad;
+      if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+      acc += x[(((size_t)b * (H + 2) + hi + 1) * (W + 2) + wi + 1) * C + c] * w[(size_t)(r * k + s) * C + c];
+    }
+  y[(((size_t)b * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * C + c] = acc;
+}
+
+// gx[hi][wi] = sum over (r, s) with (hi + pad - r, wi + pad - s) = stride * (ho, wo) of gy[ho][wo] * w[r][s]
+__global__ __launch_bounds__(256) void ref_dw_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                              int B, int H, int W, int C, int k, int stride,
+                                                              float* __restrict__ gx) {
+  const int Ho = H / stride, Wo = W / stride, pad = k / 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * H * W * C) return;
+  const int c = (int)(idx % C);
+  const int p = (int)(idx / C);
+  const int wi = p % W, hi = (p / W) % H, b = p / (W * H);
+  float acc = 0.f;
+  for (int r = 0; r < k; ++r) {
+    const int th = hi + pad - r;
+    if (th < 0 || th % stride != 0 || th / stride >= Ho) continue;
+    for (int s = 0; s < k; ++s) {
+      const int tw = wi + pad - s;
+      if (tw < 0 || tw % stride != 0 || tw / stride >= Wo) continue;
+      acc += gy[(((size_t)b * (Ho + 2) + th / stride + 1) * (Wo + 2) + tw / stride + 1) * C + c] *
+             w[(size_t)(r * k + s) * C + c];
+    }
+  }
+  gx[(((size_t)b * (H + 2) + hi + 1) * (W + 2) + wi + 1) * C + c] = acc;
+}
+
+// dw[r*k + s][c] += sum over images and output pixels of gy[ho][wo] * x[ho*stride + r - pad][wo*stride + s - pad]
+__global__ __launch_bounds__(256) void ref_dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                int B, int H, int W, int C, int k, int stride,
+                                                                float* __restrict__ dw) {
+  const int Ho = H / stride, Wo = W / stride, pad = k / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= k * k * C) return;
+  const int c = idx % C, t = idx / C;
+  const int r = t / k, s = t % k;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int ho = 0; ho < Ho; ++ho) {
+      const int hi = ho * stride + r - pad;
+      if (hi < 0 || hi >= H) continue;
+      for (int wo = 0; wo < Wo; ++wo) {
+        const int wi = wo * stride + s - pad;
+        if (wi < 0 || wi >= W) continue;
+        acc += (double)gy[(((size_t)b * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * C + c] *
+               (double)x[(((size_t)b * (H + 2) + hi + 1) * (W + 2) + wi + 1) * C + c];
+      }
+    }
+  dw[idx] += (float)acc;
+}
+
+extern "C" int nbdt_ref_bn_act_apply(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                     const float* beta, int32_t act, const float* gate, const float* residual, int32_t B,
+                                     int32_t H, int32_t W, int32_t C, float* y, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && y, "null argument");
+  const PadGeom g = make_geom(B, H, W, C);
+  const long long total = (long long)g.npix * C;
+  hipLaunchKernelGGL(ref_bn_act_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     save_mean, save_rstd, gamma, beta, act, gate, residual, g, y);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_ref_bn_act_pool(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                    const float* beta, int32_t act, const float* mul, float scale, int32_t B, int32_t H,
+                                    int32_t W, int32_t C, float* out, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && out, "null argument");
+  const PadGeom g = make_geom(B, H, W, C);
+  hipLaunchKernelGGL(ref_bn_act_pool_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, save_mean,
+                     save_rstd, gamma, beta, act, mul, scale, g, out);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+/* nbdt_bn_act_bwd (sums + elementwise pass; reduce == 0: the pass only, with the caller's dsum -- not used by the engine:
+ * its fused-sums form recomputes them here, see nbdt.ops.bn_act_bwd_apply) */
+extern "C" int nbdt_ref_bn_act_bwd(const float* gu, const float* gate, const float* gpool, const float* x,
+                                   const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                                   int32_t act, const float* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
+                                   float* dsum, float* dgamma, float* dbeta, float* gx, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && dsum && gx, "null argument");
+  NBDT_REQUIRE((gu && !gate && !gpool) || (gu && gate && gpool) || (!gu && !gate && gpool),
+               "gradient forms: gu | gu, gate, gpool | gpool");
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  hipLaunchKernelGGL(ref_bn_act_bwd_sums_kernel, dim3(C), dim3(256), 0, st, gu, gate, gpool, x, save_mean, save_rstd,
+                     gamma, beta, act, g, dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  const long long total = (long long)g.npix * C;
+  hipLaunchKernelGGL(ref_bn_act_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gu, gate, gpool,
+                     x, save_mean, save_rstd, gamma, beta, act, dsum, gx_add, g, gx);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+static int ref_check_dw(int B, int H, int W, int C, int k, int stride) {
+  NBDT_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2) &&
+               H % stride == 0 && W % stride == 0, "bad depthwise geometry");
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_ref_dwconv_fwd(const float* x, const float* w, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                                   int32_t stride, float* y, void* stream) {
+  NBDT_REQUIRE(x && w && y, "null argument");
+  if (int rc = ref_check_dw(B, H, W, C, k, stride)) return rc;
+  const long long total = (long long)B * (H / stride) * (W / stride) * C;
+  hipLaunchKernelGGL(ref_dw_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, B,
+                     H, W, C, k, stride, y);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+/* H, W: the INPUT-sized gradient being written (like nbdt_dwconv_bwd_data) */
+extern "C" int nbdt_ref_dwconv_bwd_data(const float* gy, const float* w, int32_t B, int32_t H, int32_t W, int32_t C,
+                                        int32_t k, int32_t stride, float* gx, void* stream) {
+  NBDT_REQUIRE(gy && w && gx, "null argument");
+  if (int rc = ref_check_dw(B, H, W, C, k, stride)) return rc;
+  const long long total = (long long)B * H * W * C;
+  hipLaunchKernelGGL(ref_dw_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                     w, B, H, W, C, k, stride, gx);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_ref_dwconv_bwd_weight(const float* x, const float* gy, int32_t B, int32_t H, int32_t W, int32_t C,
+                                          int32_t k, int32_t stride, float* dw, void* stream) {
+  NBDT_REQUIRE(x && gy && dw, "null argument");
+  if (int rc = ref_check_dw(B, H, W, C, k, stride)) return rc;
+  hipLaunchKernelGGL(ref_dw_bwd_weight_kernel, dim3((k * k * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, gy, B,
+                     H, W, C, k, stride, dw);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}

@@ -103,6 +103,14 @@ SIGNATURES = {
     "nbdt_ref_bn_relu_pool": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_ref_stem_conv": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_ref_stem_wgrad": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_bn_act_apply": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_bn_act_pool": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, c_float, c_int32, c_int32, c_int32, c_int32, _P,
+                                     _P]),
+    "nbdt_ref_bn_act_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P,
+                                    _P, _P, _P, _P]),
+    "nbdt_ref_dwconv_fwd": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_dwconv_bwd_data": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_dwconv_bwd_weight": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_weight_prep": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_weight_prep_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),
     "nbdt_weight_tile_batched": (c_int, [_P, _P, c_int32, c_int64, _P, _P]),

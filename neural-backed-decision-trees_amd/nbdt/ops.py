@@ -568,6 +568,10 @@ ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 
 def bn_act_apply(x, mean, rstd, gamma, beta, y, act=ACT_SWISH, gate=None, residual=None):
     B, H, W, C = _dims(x)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_act_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(gate),
+                                          ptr(residual), B, H, W, C, ptr(y), stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_act_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(gate),
                                   ptr(residual), B, H, W, C, ptr(y), stream_ptr(x.device)))
 
@@ -575,6 +579,10 @@ def bn_act_apply(x, mean, rstd, gamma, beta, y, act=ACT_SWISH, gate=None, residu
 def bn_act_pool(x, mean, rstd, gamma, beta, out, act=ACT_SWISH, mul=None, scale=None):
     B, H, W, C = _dims(x)
     scale = 1.0 / (H * W) if scale is None else scale
+    if _ref(x):
+        check(lib().nbdt_ref_bn_act_pool(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(mul), scale,
+                                         B, H, W, C, ptr(out), stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_act_pool(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(mul), scale,
                                  B, H, W, C, ptr(out), stream_ptr(x.device)))
 
@@ -582,6 +590,11 @@ def bn_act_pool(x, mean, rstd, gamma, beta, out, act=ACT_SWISH, mul=None, scale=
 def bn_act_bwd(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx, act=ACT_SWISH, gate=None,
                gpool=None, gx_add=None):
     B, H, W, C = _dims(x)
+    if _ref(x):
+        check(lib().nbdt_ref_bn_act_bwd(ptr(gu), ptr(gate), ptr(gpool), ptr(x), ptr(mean), ptr(rstd), ptr(gamma),
+                                        ptr(beta), act, ptr(gx_add), B, H, W, C, ptr(dsum), ptr(dgamma), ptr(dbeta),
+                                        ptr(gx), stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_act_bwd(ptr(gu), ptr(gate), ptr(gpool), ptr(x), ptr(mean), ptr(rstd), ptr(gamma),
                                 ptr(beta), act, ptr(gx_add), B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma),
                                 ptr(dbeta), ptr(gx), stream_ptr(x.device)))
@@ -590,12 +603,18 @@ def bn_act_bwd(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx,
 def dwconv_fwd(x, w, y, k, stride, bn_scratch=None):
     """bn_scratch: the 32-slot BN scratch; the kernel adds sum(y), sum(y^2) (fold with bn_stats(None, ...))."""
     B, H, W, C = _dims(x)
+    if _ref(x):    # (no statistics from the fp32 twin: bn_stats re-reads the tensor in reference mode)
+        check(lib().nbdt_ref_dwconv_fwd(ptr(x), ptr(w), B, H, W, C, k, stride, ptr(y), stream_ptr(x.device)))
+        return
     check(lib().nbdt_dwconv_fwd(ptr(x), ptr(w), B, H, W, C, k, stride, ptr(y), ptr(bn_scratch),
                                 stream_ptr(x.device)))
 
 
 def dwconv_bwd_data(gy, w, gx, k, stride):
     B, H, W, C = _dims(gx)
+    if _ref(gx):
+        check(lib().nbdt_ref_dwconv_bwd_data(ptr(gy), ptr(w), B, H, W, C, k, stride, ptr(gx), stream_ptr(gx.device)))
+        return
     check(lib().nbdt_dwconv_bwd_data(ptr(gy), ptr(w), B, H, W, C, k, stride, ptr(gx), stream_ptr(gx.device)))
 
 
@@ -603,6 +622,9 @@ def dwconv_bwd_data_bn(gy, w, gx, k, bn_x, mean, rstd, gamma, beta, scratch):
     """Stride-1 depthwise data gradient + the backward sums of the BatchNorm + swish that produced its input (into the
     32-slot scratch); follow with bn_act_bwd_apply."""
     B, H, W, C = _dims(gx)
+    if _ref(gx):   # the plain data gradient; the sums are recomputed by bn_act_bwd_apply's reference form
+        check(lib().nbdt_ref_dwconv_bwd_data(ptr(gy), ptr(w), B, H, W, C, k, 1, ptr(gx), stream_ptr(gx.device)))
+        return
     check(lib().nbdt_dwconv_bwd_data_bn(ptr(gy), ptr(w), B, H, W, C, k, ptr(gx), ptr(bn_x), ptr(mean), ptr(rstd),
                                         ptr(gamma), ptr(beta), ptr(scratch), stream_ptr(gx.device)))
 
@@ -610,6 +632,11 @@ def dwconv_bwd_data_bn(gy, w, gx, k, bn_x, mean, rstd, gamma, beta, scratch):
 def bn_act_bwd_apply(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbeta, gx, act=ACT_SWISH, gx_add=None):
     """bn_act_bwd without its reduction pass (the producing kernel filled the slots)."""
     B, H, W, C = _dims(x)
+    if _ref(x):    # reference mode: sums + elementwise pass (dwconv_bwd_data_bn's twin left no sums)
+        check(lib().nbdt_ref_bn_act_bwd(ptr(gu), None, None, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act,
+                                        ptr(gx_add), B, H, W, C, ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx),
+                                        stream_ptr(x.device)))
+        return
     check(lib().nbdt_bn_act_bwd_apply(ptr(gu), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(gx_add),
                                       B, H, W, C, ptr(scratch), ptr(dsum), ptr(dgamma), ptr(dbeta), ptr(gx),
                                       stream_ptr(x.device)))
@@ -617,6 +644,9 @@ def bn_act_bwd_apply(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbet
 
 def dwconv_bwd_weight(x, gy, dw, k, stride):
     B, H, W, C = _dims(x)
+    if _ref(x):
+        check(lib().nbdt_ref_dwconv_bwd_weight(ptr(x), ptr(gy), B, H, W, C, k, stride, ptr(dw), stream_ptr(x.device)))
+        return
     check(lib().nbdt_dwconv_bwd_weight(ptr(x), ptr(gy), B, H, W, C, k, stride, ptr(dw), stream_ptr(x.device)))
 
 

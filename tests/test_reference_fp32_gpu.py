@@ -179,3 +179,89 @@ def test_whole_step_in_fp32_storage_equals_the_fp32_oracle(case, schedule, pkg_d
 def TM_state(make_ref, seed):
     torch.manual_seed(seed)
     return {k: v.clone() for k, v in make_ref().state_dict().items()}
+
+
+@pytest.mark.parametrize("schedule", ["two-streams", "one-stream"])
+def test_efficientnet_b0_whole_step_in_fp32_storage_equals_the_fp32_oracle(schedule, pkg_dir):
+    """the EfficientNet-B0 engine (depthwise convs, BatchNorm + swish, squeeze-and-excitation, skip
+    connections, 81 convolutions) had only the bf16-storage comparison -- logits to 5-6 % of their scale after ~80 storage
+    points.  With fp32 storage the SAME forward() / backward() -- same launch order, second stream for the weight
+    gradients, lagged events, alternating gradient buffers, fused-statistics protocol -- routes every launch on an
+    activation tensor to its fp32 twin (csrc/ref_fp32.hip: nbdt_ref_bn_act_*, nbdt_ref_dwconv_*; the SE gate, dropout and
+    the classifier are fp32 in the product path already), and the whole training step must agree with the fp32 CPU oracle
+    to 1e-3 relative L2 per parameter gradient.  Swish has no kink, so unlike the ReLU networks above there are no ties:
+    every batch has to meet the bar.  Dropout off (both paths deterministic functions of the same weights)."""
+    from nbdt.engine_effnet import EfficientNetEngine
+    classes, size, B = 10, 64, 8
+    otree = O.OracleTree(*O.default_paths("CIFAR10", "induced-ResNet18", pkg_dir))
+    crit = SoftTreeSupLoss(dataset="CIFAR10", criterion=nn.CrossEntropyLoss(), hierarchy="induced-ResNet18")
+    torch.manual_seed(5)
+    init = {k: v.clone() for k, v in TM.EfficientNetB0(num_classes=classes, dropout_rate=0.0).state_dict().items()}
+    eng = EfficientNetEngine(num_classes=classes, dropout_rate=0.0, device=DEV)
+    if schedule == "one-stream":
+        eng.set_overlap(False)
+    eng.set_reference_fp32(True)
+    assert eng.act_dtype == torch.float32
+    worst_all = 0.0
+    for seed in (31, 32):
+        ref = TM.EfficientNetB0(num_classes=classes, dropout_rate=0.0)
+        ref.load_state_dict(init)
+        eng.load_state_dict(init)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, 3, size, size, generator=g)
+        y = torch.randint(0, classes, (B,), generator=g)
+        z_ref, loss_ref, g_ref = _oracle(ref, otree, x, y, 1.0)
+        seen = {"dw": 0, "act": 0}
+        real_dw, real_act = ops.dwconv_fwd, ops.bn_act_apply
+
+        def spy_dw(xx, *a, **k):
+            seen["dw"] += 1
+            assert xx.dtype == torch.float32
+            return real_dw(xx, *a, **k)
+
+        def spy_act(xx, *a, **k):
+            seen["act"] += 1
+            assert xx.dtype == torch.float32
+            return real_act(xx, *a, **k)
+
+        ops.dwconv_fwd, ops.bn_act_apply = spy_dw, spy_act
+        try:
+            eng.zero_grad()
+            z = eng.forward(x.to(DEV), training=True)
+            loss, gz = crit.loss_and_grad(z, y.to(DEV))
+            eng.backward(gz)
+            torch.cuda.synchronize()
+        finally:
+            ops.dwconv_fwd, ops.bn_act_apply = real_dw, real_act
+        assert seen["dw"] == len(eng.units) == 16 and seen["act"] >= 3 * 15
+        grads = {k: v.clone() for k, v in eng.named_params("grad").items()}
+        scale = z_ref.abs().max().item()
+        assert (z.float().cpu() - z_ref).abs().max().item() < 1e-4 * scale
+        assert abs(loss.item() - loss_ref) < 1e-5 * abs(loss_ref), (loss.item(), loss_ref)
+        assert set(grads) == set(g_ref)
+        # (a BatchNorm shift that feeds conv -> BatchNorm has a mathematically zero gradient: compare those absolutely)
+        gmax = max(v.abs().max().item() for v in g_ref.values())
+        errs = []
+        for n in g_ref:
+            if g_ref[n].norm().item() < 1e-6 * gmax:
+                assert grads[n].float().cpu().norm().item() < 1e-4 * gmax, n
+                continue
+            errs.append((_rel_l2(grads[n], g_ref[n]), n))
+        errs.sort()
+        worst, median = errs[-1], errs[len(errs) // 2][0]
+        worst_all = max(worst_all, worst[0])
+        print(f"[efficientnet_b0 / {schedule} / inputs {seed}] loss {loss.item():.6f} vs {loss_ref:.6f}; parameter-gradient "
+              f"rel-L2 over {len(errs)} tensors: worst {worst[0]:.2e} ({worst[1]}), median {median:.2e}")
+        assert worst[0] < TOL, worst
+        sd, sd_ref = eng.state_dict(), ref.state_dict()
+        for k in sd_ref:
+            if k.endswith("running_var") or k.endswith("running_mean"):
+                assert _rel_l2(sd[k], sd_ref[k]) < 1e-4, k
+    # the same object back in bf16 storage: the product kernels again, at their usual distance
+    eng.set_reference_fp32(False)
+    eng.load_state_dict(init)
+    eng.zero_grad()
+    z_b = eng.forward(x.to(DEV), training=True)
+    assert z_b.dtype == torch.float32 and eng.buf("t0", B, size // 2, size // 2, 32).dtype == torch.bfloat16
+    assert (z_b.float().cpu() - z_ref).abs().max().item() < 0.1 * z_ref.abs().max().item()
+    assert (z_b.float().cpu() - z_ref).abs().max().item() > 10 * 1e-4 * worst_all * z_ref.abs().max().item()

@@ -254,9 +254,10 @@ def test_efficientnet_b0_whole_step_in_fp32_storage_equals_the_fp32_oracle(sched
               f"rel-L2 over {len(errs)} tensors: worst {worst[0]:.2e} ({worst[1]}), median {median:.2e}")
         assert worst[0] < TOL, worst
         sd, sd_ref = eng.state_dict(), ref.state_dict()
-        for k in sd_ref:
+        for k in sd_ref:       # (a conv fed by a BatchNorm shift has a mathematically zero mean: absolute floor)
             if k.endswith("running_var") or k.endswith("running_mean"):
-                assert _rel_l2(sd[k], sd_ref[k]) < 1e-4, k
+                a, b = sd[k].float().cpu(), sd_ref[k].float().cpu()
+                assert (a - b).norm().item() < 1e-4 * b.norm().item() + 1e-6, k
     # the same object back in bf16 storage: the product kernels again, at their usual distance
     eng.set_reference_fp32(False)
     eng.load_state_dict(init)

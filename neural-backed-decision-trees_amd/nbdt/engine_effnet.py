@@ -174,6 +174,42 @@ class EfficientNetEngine(_Engine):
     def _vec(self, key, B, n):
         return self._tensor(key, (B, n))
 
+    def algorithmic_bytes(self, B, size):
+        """HBM bytes one training step of THIS schedule has to move if every pass reads each of its input tensors once and
+        writes each output once (bf16 activations / gradients, padded channel counts; weights, statistics and the [B, C]
+        vectors of the SE branch are noise and left out).  What bench.py prices EfficientNet-B0 against: round 4 used
+        2 x the resident buffers (12.6 GB at 128 x 224 x 224), which ignores that backward re-reads every stored
+        activation and that several passes read two tensors -- the PMC counters said 36 GB.  Per unit, with X / E / D / O
+        the unit's input, expanded (before the depthwise conv), depthwise-output and output tensors:
+          forward   expand conv X + E | BatchNorm + swish 2E | depthwise E + D | squeeze D | scale 2D | project D + O |
+                    BatchNorm (+ skip) 2O (+ X)
+          backward  bn3 5O | project weight gradient D + O, data gradient O + D | dL/dgate 2D | bn2 + SE 5D | depthwise
+                    weight gradient E + D, data gradient + bn1 sums D + 2E | bn1 elementwise 3E | expand weight gradient
+                    X + E, data gradient E + X (+ X when it accumulates onto the skip gradient)"""
+        h = w = size // 2
+        e = lambda hh, ww, c: 2 * B * hh * ww * _pad32(c)       # bytes of one bf16 tensor
+        stem = e(h, w, self.stem_c)
+        total = 12 * B * size * size + 2 * stem + 2 * stem      # image in, stem conv out, BatchNorm + swish (read + write)
+        total += 5 * stem + 12 * B * size * size + stem         # backward of that BatchNorm, stem weight gradient
+        for u in self.units:
+            s = u["stride"]
+            ho, wo = h // s, w // s
+            X, O = e(h, w, u["cin"]), e(ho, wo, u["cout"])
+            E, D = e(h, w, u["mid"]), e(ho, wo, u["mid"])
+            res = X if u["residual"] else 0
+            if u["conv1"] is not None:
+                fwd = (X + E) + 2 * E + (E + D) + D + 2 * D + (D + O) + 2 * O + res
+                bwd = 5 * O + (D + O) + (O + D) + 2 * D + 5 * D + (E + D) + (D + 2 * E) + 3 * E + (X + E) + (E + X) + res
+            else:       # stage 1: depthwise on the unit's input, no expand conv
+                fwd = (X + D) + D + 2 * D + (D + O) + 2 * O + res
+                bwd = 5 * O + (D + O) + (O + D) + 2 * D + 5 * D + (X + D) + (D + X)
+            total += fwd + bwd
+            h, w = ho, wo
+        F, L = e(h, w, self.feat_c), e(h, w, self.units[-1]["cout"])
+        total += (L + F) + F                                    # final conv, BatchNorm + swish + pool (reads only)
+        total += 4 * F + F + (L + F) + (F + L)                  # its backward (pool form: no gradient tensor read), conv grads
+        return int(total)
+
     # ------------------------------------------------------------------ forward
     def forward(self, img, training=None):
         training = self.training if training is None else training

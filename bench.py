@@ -496,7 +496,7 @@ def main():
         w = summ.get("conv_wgrad")
         if w:
             out["roofline_wgrad"] = {"bound": "mfma",
-                                     "kernel": "conv_wgrad: conv_wgrad_pp_kernel (22 of 27 launches) / "
+                                     "kernel": "conv_wgrad: conv_wgrad_ks_kernel (22 of 27 launches) / "
                                                "conv_wgrad_dma_kernel (strided, 1x1, 16-channel input)",
                                      "achieved": round(w["tflops"], 1),
                                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

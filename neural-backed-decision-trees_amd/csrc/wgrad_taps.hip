@@ -652,6 +652,572 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pp_kernel(nbdt::WgradTapsPa
   else run(std::integral_constant<int, NT0>{}, std::integral_constant<int, 9 - NT0>{});
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K-split form (round 5): the two wave groups split the PIXELS of a stage, not the taps.
+//
+// What bounds conv_wgrad_pp_kernel (profiles/r05_wgrad_segments.txt, r05_wgrad_pp3_ab.txt): a CU completes one
+// ds_read_b64_tr_b16 per ~8 cycles however many waves issue them, and a stage of the tap-split kernel needs 8 waves x 32
+// reads = 256 of them = 2050 cycles for 1440 cycles of matrix pipe -- the measured 2120.  (The 12-wave, one-kernel-row-per-
+// group kernel below does 312 reads per stage and is 22 % slower: exactly the ratio.)  The redundancy is in the tiling: a
+// gy fragment is read by the two groups AND the two cin halves, four times per stage.
+// Here a wave owns 80 couts x 16 cins x ALL NINE taps (180 accumulator registers) and the groups take the two 32-pixel
+// K chunks of a stage: group 0 chunk 0, group 1 chunk 1, one barrier apart as before.  A wave reads its gy fragments once
+// for nine taps (10 reads) and one 12-pixel run per kernel row (9 reads): 8 x 19 = 152 reads per stage, 1220 cycles,
+// under the 1440 of the pipe.  All reads are in the load segment; the MFMA segment is 45 MFMAs and address arithmetic.
+// The two groups' partial sums meet at the end: through LDS, lane to lane with the partner wave (w ^ 4), in two rounds
+// (taps 0-4 to group 0, taps 5-8 to group 1: 102 + 82 KB of the ring, which is dead by then), so that the fp32 atomics
+// that follow are the same 100 / 80 per lane as before -- the split count, i.e. the atomic volume, does not change.
+// Ring, prefetch distance, DMA pieces, swizzles and the vmcnt protocol are conv_wgrad_pp_kernel's.
+template <int WM>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ks_kernel(nbdt::WgradTapsParams p) {
+  constexpr int CG = 32 * WM;
+  constexpr int KSP = 64;
+  constexpr int PG = 2 * CG;
+  constexpr int XS = 144;
+  constexpr int G_BYTES = KSP * PG;
+  constexpr int X_BYTES = XS * 64;
+  constexpr int STAGE = G_BYTES + X_BYTES;
+  constexpr int G_INSTR = G_BYTES / 1024;
+  constexpr int X_INSTR = XS / 16;
+  constexpr int IPG = (G_INSTR + 7) / 8;
+  constexpr int NSLOT = 5, PD = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const nbdt_wgrad_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;    // group = K chunk of every stage
+  const int wm = w4 >> 1, wn = w4 & 1;
+
+  const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if (item >= p.items) return;
+  const int n_tiles = p.items / p.splits;
+  const int tile = item % n_tiles;
+  const int split = item / n_tiles;
+  const int co_blk = tile / p.n_ci_blocks;
+  const int ci_blk = tile - co_blk * p.n_ci_blocks;
+  const int co0 = co_blk * CG;
+  const int ci0 = ci_blk * 32;
+  const int s_begin = split * p.stages_per_split;
+  int s_end = s_begin + p.stages_per_split;
+  s_end = s_end < p.stages ? s_end : p.stages;
+  if (s_begin >= s_end) return;
+  const int n_st = s_end - s_begin;
+
+#define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
+  const int g_bs = NBDT_PIN(d.g_bs), g_hs = NBDT_PIN(d.g_hs), g_ws = NBDT_PIN(d.g_ws);
+  const int x_bs = NBDT_PIN(d.x_bs), x_hs = NBDT_PIN(d.x_hs), x_ws = NBDT_PIN(d.x_ws);
+  const int rs = NBDT_PIN(p.rs), cs = NBDT_PIN(p.cs), hw2 = NBDT_PIN(p.hw2), hp_n = NBDT_PIN(p.hp);
+  FastDiv dspr, drg;
+  dspr.mul = NBDT_PIN(p.div_spr.mul); dspr.sh = NBDT_PIN(p.div_spr.sh); dspr.d = NBDT_PIN(p.div_spr.d);
+  drg.mul = NBDT_PIN(p.div_rg.mul); drg.sh = NBDT_PIN(p.div_rg.sh); drg.d = NBDT_PIN(p.div_rg.d);
+  const unsigned long long gy_u = (unsigned long long)p.gy, x_u = (unsigned long long)p.x;
+  const bf16_t* gy_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(gy_u >> 32)) << 32) |
+                                          (unsigned)NBDT_PIN((unsigned)gy_u));
+  const bf16_t* x_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(x_u >> 32)) << 32) |
+                                         (unsigned)NBDT_PIN((unsigned)x_u));
+#undef NBDT_PIN
+
+  // ---- LDS stage image, DMA pieces: conv_wgrad_pp_kernel's
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned g_voff[IPG];
+#pragma unroll
+  for (int k = 0; k < IPG; ++k) {
+    const int pos = (wave + 8 * k) * 1024 + lane * 16;
+    int px = pos / PG;
+    const int j = (pos - px * PG) >> 4;
+    const int src_chunk = j ^ (((px >> 3) & 1) << 1);
+    px = px < KSP ? px : KSP - 1;
+    g_voff[k] = (unsigned)((px / cs) * g_hs + (px % cs) * g_ws + d.g_base + co0 + src_chunk * 8) * 2u;
+  }
+  unsigned x_voff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int slot = 16 * (wave + 8 * k) + (lane >> 2);
+    const int hp = slot < hp_n ? slot : hp_n - 1;
+    const int hrow = hp / hw2, hcol = hp - hrow * hw2;
+    const int src_chunk = (lane & 3) ^ ((((hcol >> 3) ^ hrow) & 1) << 1);
+    x_voff[k] = (unsigned)(hrow * x_hs + hcol * x_ws + d.x_base + ci0 + src_chunk * 8) * 2u;
+  }
+  int n_mine = 1 + (wave + 8 < X_INSTR ? 1 : 0);
+#pragma unroll
+  for (int k = 0; k < IPG; ++k) n_mine += (wave + 8 * k < G_INSTR) ? 1 : 0;
+
+  auto stage_off = [&](int stage, int& g_stage, int& x_stage) {
+    const unsigned st = (unsigned)stage;
+    const unsigned q1m = __umulhi(st, dspr.mul) >> dspr.sh;
+    const unsigned q1 = dspr.d == 1 ? st : q1m;
+    const int sc = (int)(st - q1 * dspr.d);
+    const unsigned bm = __umulhi(q1, drg.mul) >> drg.sh;
+    const unsigned b = drg.d == 1 ? q1 : bm;
+    const int rg = (int)(q1 - b * drg.d);
+    const int r0 = rg * rs, c0 = sc * cs;
+    g_stage = (int)b * g_bs + r0 * g_hs + c0 * g_ws;
+    x_stage = (int)b * x_bs + r0 * x_hs + c0 * x_ws;
+  };
+  auto issue = [&](int slot_i, int g_stage, int x_stage) {
+    const unsigned dst0 = lds_base + slot_i * STAGE;
+#pragma unroll
+    for (int k = 0; k < IPG; ++k)
+      if (wave + 8 * k < G_INSTR) glds16_s(gy_base + g_stage, g_voff[k], dst0 + (wave + 8 * k) * 1024);
+    glds16_s(x_base + x_stage, x_voff[0], dst0 + G_BYTES + wave * 1024);
+    if (wave + 8 < X_INSTR) glds16_s(x_base + x_stage, x_voff[1], dst0 + G_BYTES + (wave + 8) * 1024);
+  };
+
+  f32x4 acc[9][WM];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int a = 0; a < WM; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transpose-read addressing: this group's K chunk = pixels 32 grp .. 32 grp + 31 of every stage
+  typedef const __attribute__((address_space(3))) unsigned char* lds_cptr;
+  typedef __attribute__((address_space(3))) s16x4* lds_tr;
+  const lds_cptr smem3 = (lds_cptr)smem;
+  const int g4 = lane >> 4, t16 = lane & 15;
+  const int pr = t16 >> 2;
+  const int c8 = (t16 & 3) * 8;
+  int g_lane_off[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+    g_lane_off[a] = (grp * 32 + 8 * g4 + pr) * PG + (((wm * WM + a) ^ (g4 & 1)) * 32) + c8;   // ((32 grp + 8 g4 + j) >> 3) & 1 == g4 & 1
+  int xrel[3][3];                              // [kernel row][4-pixel block of the 12-pixel run]
+  {
+    const int k = grp * 32 + 8 * g4;
+    const int row0 = k / cs, col0 = k - row0 * cs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int hrow = row0 + r, hcol = col0 + 4 * q + pr;
+        const int hs = hrow * hw2 + hcol;
+        xrel[r][q] = G_BYTES + c8 + ((hs << 6) | (((((hcol >> 3) ^ hrow) ^ wn) & 1) << 5));
+      }
+  }
+
+  // ---- prologue
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (u < n_st) {
+      int gs, xs;
+      stage_off(s_begin + u, gs, xs);
+      issue(u, gs, xs);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                // bP
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  lds_cptr xa[3][3];
+  lds_cptr ga[2];
+  auto prepare = [&](int slot_i) {
+    int off = slot_i * STAGE;
+    asm volatile("" : "+s"(off));
+    const lds_cptr base = smem3 + off;
+    ga[0] = base + g_lane_off[0];
+    ga[1] = base + g_lane_off[1];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) xa[r][q] = base + xrel[r][q];
+  };
+  prepare(0);
+  int slot_n = 1 % NSLOT, slot_d = PD % NSLOT;
+  int g_next = 0, x_next = 0;
+  if (PD < n_st) stage_off(s_begin + PD, g_next, x_next);
+
+  for (int u = 0; u < n_st; ++u) {
+    // ================= L(u): this wave's fragments of its chunk -> registers, its pieces of stage u + PD =================
+    bf16x8 gf[WM];
+    u32x2 xw[3][3];
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+      const lds_cptr a0 = ga[a & 1] + (a >> 1) * 64;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * PG));
+      gf[a] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        xw[r][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[r][q]));
+    // stage u+1 (issued two load segments ago) must be in LDS before the next barrier; the stage issued since may fly
+    if (u + PD <= n_st) {
+      switch (n_mine) {
+#define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+        NBDT_CASE(1) NBDT_CASE(2) NBDT_CASE(3) NBDT_CASE(4) NBDT_CASE(5)
+#undef NBDT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (u + PD < n_st) issue(slot_d, g_next, x_next);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= M(u): 9 x WM MFMAs; their shadow prepares L(u+1) =================
+    __builtin_amdgcn_s_setprio(1);
+    prepare(slot_n);
+    stage_off(s_begin + u + 1 + PD, g_next, x_next);       // (past the end: computed, never used)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int r = t / 3, sft = t % 3;
+      const u32x2 A = xw[r][0], B = xw[r][1], C = xw[r][2];
+      u32x4_t v;
+      if (sft == 0) v = u32x4_t{A[0], A[1], B[0], B[1]};
+      else if (sft == 2) v = u32x4_t{A[1], B[0], B[1], C[0]};
+      else v = u32x4_t{__builtin_amdgcn_alignbit(A[1], A[0], 16), __builtin_amdgcn_alignbit(B[0], A[1], 16),
+                       __builtin_amdgcn_alignbit(B[1], B[0], 16), __builtin_amdgcn_alignbit(C[0], B[1], 16)};
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+        acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf, acc[t][a], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 9 * WM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(xa[r][0]), "+v"(xa[r][1]), "+v"(xa[r][2]));
+    asm volatile("" : "+v"(ga[0]), "+v"(ga[1]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot_n = slot_n + 1 == NSLOT ? 0 : slot_n + 1;
+    slot_d = slot_d + 1 == NSLOT ? 0 : slot_d + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  // ---- the two groups' partial sums meet: partner wave w ^ 4 holds the same (cout, cin) tile of the other K chunks.
+  // Lane to lane through LDS ([f32x4 index][lane] x 16 B: lane-linear, conflict-free), two rounds; the ring is dead (every
+  // wave is past its last read and no LDS-DMA is in flight: the last load segments drained vmcnt).
+  __builtin_amdgcn_sched_barrier(0);
+#ifndef NBDT_WKS_NO_EXCHANGE
+  {
+    typedef __attribute__((address_space(3))) f32x4* lds_f4;
+    const lds_f4 ex = (lds_f4)(__attribute__((address_space(3))) unsigned char*)smem + (w4 * (5 * WM) * 64 + lane);
+    if (grp == 1) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int a = 0; a < WM; ++a) ex[(t * WM + a) * 64] = acc[t][a];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[t][a] += ex[(t * WM + a) * 64];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int t = 5; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < WM; ++a) ex[((t - 5) * WM + a) * 64] = acc[t][a];
+    }
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+      for (int t = 5; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < WM; ++a) acc[t][a] += ex[((t - 5) * WM + a) * 64];
+    }
+  }
+#endif
+  // ---- epilogue: group 0 owns taps 0-4, group 1 taps 5-8; co = co0 + (wm*WM + a)*16 + 4*g4 + r ; ci = ci0 + wn*16 + t16
+  const int ci = ci0 + wn * 16 + t16;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#ifndef NBDT_WKS_NO_EXCHANGE                   // (debug build: no exchange, both groups add all their partial sums)
+    if ((t < 5) != (grp == 0)) continue;       // wave-uniform
+#endif
+    const int w_tap = d.w_tap[t];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
+        atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 12-wave form (round 5): THREE wave groups, one kernel ROW each (taps 3g, 3g+1, 3g+2), three waves per SIMD.
+//
+// Why.  s_memtime stamps of the 8-wave kernel above (profiles/r05_wgrad_segments.txt): a wave's ds_read_b64_tr_b16
+// complete one per ~38 cycles whatever surrounds them (16 reads: 610 cycles), its 3-5 LDS-DMA pieces cost 270 cycles of
+// issue, and both sit in the load segment (970 cycles) while the partner's MFMA segment is 850 / 680 cycles of matrix
+// pipe: the per-WAVE serial work (32 reads + 45 MFMAs + pieces per stage = 2200 cycles) sets the 2120-cycle stage, not
+// the pipe (1440).  With one kernel row per wave the x operand of its three taps is ONE 12-pixel run (3 reads per K
+// chunk), so a wave has 26 reads + 30 MFMAs + 1-3 pieces per stage (~1630 cycles), and with three waves per SIMD two of
+// them are in load phases while the third issues MFMAs:
+//     group g:   [g idle slots]  P1(0) b P2(0) b M(0) b  P1(1) b P2(1) b M(1) b ...   [2 - g idle slots]
+//   P1(u): 13 transpose reads of K chunk 0 of stage u | this wave's pieces of stage u+3 | vmcnt: stage u+1 landed
+//   P2(u): 13 transpose reads of K chunk 1
+//   M(u):  30 MFMAs (no LDS access), the address arithmetic of stage u+1 in their shadow
+// Every slot ends in ONE s_barrier executed by all 12 waves; in any slot exactly one group is in each phase.
+// Hazards.  Stage u+3 overwrites the ring slot of stage u-2 (5 slots); its last reader is group 2's P2(u-2) in slot
+// 3u-3, drained (lgkmcnt) before that slot's barrier; the first writer is group 0's P1(u) in slot 3u.  A wave retires
+// (vmcnt) in P1(v) what it issued in P1(v-2) -- stage v+1, first read in slot 3v+3 by group 0 -- and P1(v) of every
+// group lies in slots 3v .. 3v+2, a barrier before.  Stages alive in slot 3u: u-1 (group 2 reading), u, u+1, u+2 and
+// u+3 arriving: the five slots.
+template <int WM>
+__global__ __launch_bounds__(768, 3) void conv_wgrad_pp3_kernel(nbdt::WgradTapsParams p) {
+  constexpr int CG = 32 * WM;
+  constexpr int KSP = 64, KK = KSP / 32;
+  constexpr int PG = 2 * CG;
+  constexpr int XS = 144;
+  constexpr int G_BYTES = KSP * PG;
+  constexpr int X_BYTES = XS * 64;
+  constexpr int STAGE = G_BYTES + X_BYTES;
+  constexpr int G_INSTR = G_BYTES / 1024;      // 4 * WM gy pieces per stage
+  constexpr int X_INSTR = XS / 16;             // 9
+  constexpr int NWV = 12;
+  constexpr int IPG = (G_INSTR + NWV - 1) / NWV;
+  constexpr int NSLOT = 5, PD = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const nbdt_wgrad_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;    // group = kernel row
+  const int wm = w4 >> 1, wn = w4 & 1;
+
+  const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if (item >= p.items) return;
+  const int n_tiles = p.items / p.splits;      // tile fastest: blocks sharing a pixel range sit on one XCD
+  const int tile = item % n_tiles;
+  const int split = item / n_tiles;
+  const int co_blk = tile / p.n_ci_blocks;
+  const int ci_blk = tile - co_blk * p.n_ci_blocks;
+  const int co0 = co_blk * CG;
+  const int ci0 = ci_blk * 32;
+  const int s_begin = split * p.stages_per_split;
+  int s_end = s_begin + p.stages_per_split;
+  s_end = s_end < p.stages ? s_end : p.stages;
+  if (s_begin >= s_end) return;
+  const int n_st = s_end - s_begin;
+
+#define NBDT_PIN(x) __builtin_amdgcn_readfirstlane(x)
+  const int g_bs = NBDT_PIN(d.g_bs), g_hs = NBDT_PIN(d.g_hs), g_ws = NBDT_PIN(d.g_ws);
+  const int x_bs = NBDT_PIN(d.x_bs), x_hs = NBDT_PIN(d.x_hs), x_ws = NBDT_PIN(d.x_ws);
+  const int rs = NBDT_PIN(p.rs), cs = NBDT_PIN(p.cs), hw2 = NBDT_PIN(p.hw2), hp_n = NBDT_PIN(p.hp);
+  FastDiv dspr, drg;
+  dspr.mul = NBDT_PIN(p.div_spr.mul); dspr.sh = NBDT_PIN(p.div_spr.sh); dspr.d = NBDT_PIN(p.div_spr.d);
+  drg.mul = NBDT_PIN(p.div_rg.mul); drg.sh = NBDT_PIN(p.div_rg.sh); drg.d = NBDT_PIN(p.div_rg.d);
+  const unsigned long long gy_u = (unsigned long long)p.gy, x_u = (unsigned long long)p.x;
+  const bf16_t* gy_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(gy_u >> 32)) << 32) |
+                                          (unsigned)NBDT_PIN((unsigned)gy_u));
+  const bf16_t* x_base = (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(x_u >> 32)) << 32) |
+                                         (unsigned)NBDT_PIN((unsigned)x_u));
+#undef NBDT_PIN
+
+  // ---- LDS stage image and its swizzles: exactly conv_wgrad_pp_kernel's (gy [64 px][CG], x [144 slots][64 B])
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned g_voff[IPG];                        // gy pieces {wave + 12 k}
+#pragma unroll
+  for (int k = 0; k < IPG; ++k) {
+    const int pos = (wave + NWV * k) * 1024 + lane * 16;
+    int px = pos / PG;
+    const int j = (pos - px * PG) >> 4;
+    const int src_chunk = j ^ (((px >> 3) & 1) << 1);
+    px = px < KSP ? px : KSP - 1;              // (ids past the tile are never issued)
+    g_voff[k] = (unsigned)((px / cs) * g_hs + (px % cs) * g_ws + d.g_base + co0 + src_chunk * 8) * 2u;
+  }
+  unsigned x_voff;                             // x piece {wave} (waves 0 .. 8): halo slots [16 wave, +16) x 64 B
+  {
+    const int slot = 16 * wave + (lane >> 2);
+    const int hp = slot < hp_n ? slot : hp_n - 1;          // unused slots re-fetch the last halo pixel
+    const int hrow = hp / hw2, hcol = hp - hrow * hw2;
+    const int src_chunk = (lane & 3) ^ ((((hcol >> 3) ^ hrow) & 1) << 1);
+    x_voff = (unsigned)(hrow * x_hs + hcol * x_ws + d.x_base + ci0 + src_chunk * 8) * 2u;
+  }
+  int n_mine = wave < X_INSTR ? 1 : 0;         // DMA instructions this wave issues per stage (1 .. 3 at WM = 5)
+#pragma unroll
+  for (int k = 0; k < IPG; ++k) n_mine += (wave + NWV * k < G_INSTR) ? 1 : 0;
+
+  auto stage_off = [&](int stage, int& g_stage, int& x_stage) {
+    const unsigned st = (unsigned)stage;       // (branch-free divisions: a branch would split the MFMA phase)
+    const unsigned q1m = __umulhi(st, dspr.mul) >> dspr.sh;
+    const unsigned q1 = dspr.d == 1 ? st : q1m;
+    const int sc = (int)(st - q1 * dspr.d);
+    const unsigned bm = __umulhi(q1, drg.mul) >> drg.sh;
+    const unsigned b = drg.d == 1 ? q1 : bm;
+    const int rg = (int)(q1 - b * drg.d);
+    const int r0 = rg * rs, c0 = sc * cs;
+    g_stage = (int)b * g_bs + r0 * g_hs + c0 * g_ws;
+    x_stage = (int)b * x_bs + r0 * x_hs + c0 * x_ws;
+  };
+  auto issue = [&](int slot_i, int g_stage, int x_stage) {
+    const unsigned dst0 = lds_base + slot_i * STAGE;
+#pragma unroll
+    for (int k = 0; k < IPG; ++k)
+      if (wave + NWV * k < G_INSTR) glds16_s(gy_base + g_stage, g_voff[k], dst0 + (wave + NWV * k) * 1024);
+    if (wave < X_INSTR) glds16_s(x_base + x_stage, x_voff, dst0 + G_BYTES + wave * 1024);
+  };
+
+  f32x4 acc[3][WM];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int a = 0; a < WM; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transpose-read addressing (conv_wgrad_pp_kernel's K order: 8 consecutive pixels per 16-lane group)
+  typedef const __attribute__((address_space(3))) unsigned char* lds_cptr;
+  typedef __attribute__((address_space(3))) s16x4* lds_tr;
+  const lds_cptr smem3 = (lds_cptr)smem;
+  const int g4 = lane >> 4, t16 = lane & 15;
+  const int pr = t16 >> 2;
+  const int c8 = (t16 & 3) * 8;
+  int g_lane_off[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) g_lane_off[a] = (8 * g4 + pr) * PG + (((wm * WM + a) ^ (g4 & 1)) * 32) + c8;
+  int xrel[KK][3];                             // this group's kernel row: halo row = pixel row + grp
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int k = kk * 32 + 8 * g4;
+    const int row0 = k / cs, col0 = k - row0 * cs;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int hrow = row0 + grp, hcol = col0 + 4 * q + pr;
+      const int hs = hrow * hw2 + hcol;
+      xrel[kk][q] = G_BYTES + c8 + ((hs << 6) | (((((hcol >> 3) ^ hrow) ^ wn) & 1) << 5));
+    }
+  }
+
+  // ---- prologue: stages 0 .. PD-1, all landed before the first read
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (u < n_st) {
+      int gs, xs;
+      stage_off(s_begin + u, gs, xs);
+      issue(u, gs, xs);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                // bP
+  for (int i = 0; i < grp; ++i) __builtin_amdgcn_s_barrier();     // this group's idle slots at the start
+  __builtin_amdgcn_sched_barrier(0);
+
+  lds_cptr xa[KK][3];
+  lds_cptr ga[2];
+  auto prepare = [&](int slot_i) {
+    int off = slot_i * STAGE;
+    asm volatile("" : "+s"(off));
+    const lds_cptr base = smem3 + off;
+    ga[0] = base + g_lane_off[0];
+    ga[1] = base + g_lane_off[1];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) xa[kk][q] = base + xrel[kk][q];
+  };
+  prepare(0);
+  int slot_n = 1 % NSLOT, slot_d = PD % NSLOT;
+  int g_next = 0, x_next = 0;                  // tile offsets of stage u + PD, computed in M(u-1)
+  if (PD < n_st) stage_off(s_begin + PD, g_next, x_next);
+
+  for (int u = 0; u < n_st; ++u) {
+    bf16x8 gf[KK][WM];
+    u32x2 xw[KK][3];
+    auto read_chunk = [&](auto kk_c) {
+      constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+      for (int a = 0; a < WM; ++a) {
+        const lds_cptr a0 = ga[a & 1] + ((a >> 1) * 64 + kk * 32 * PG);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(a0 + 4 * PG));
+        gf[kk][a] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        xw[kk][q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)xa[kk][q]));
+    };
+    auto x_frag = [&](int kk, int sft) {       // pixels sft .. sft + 7 of the run
+      const u32x2 A = xw[kk][0], B = xw[kk][1], C = xw[kk][2];
+      u32x4_t v;
+      if (sft == 0) v = u32x4_t{A[0], A[1], B[0], B[1]};
+      else if (sft == 2) v = u32x4_t{A[1], B[0], B[1], C[0]};
+      else v = u32x4_t{__builtin_amdgcn_alignbit(A[1], A[0], 16), __builtin_amdgcn_alignbit(B[0], A[1], 16),
+                       __builtin_amdgcn_alignbit(B[1], B[0], 16), __builtin_amdgcn_alignbit(C[0], B[1], 16)};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    // ================= P1(u): K chunk 0 -> registers, this wave's pieces of stage u + PD =================
+    const bool dma_now = u + PD < n_st;
+    read_chunk(std::integral_constant<int, 0>{});
+    if (dma_now) issue(slot_d, g_next, x_next);
+    {
+      // stage u+1 (issued in P1(u-2)) must be in LDS before this slot's barrier; what P1(u-1) and this phase issued
+      // (stages u+2, u+3: n_mine pieces each, fewer near the end) may stay in flight
+      const int fly = (dma_now ? n_mine : 0) + (u + PD - 1 < n_st ? n_mine : 0);
+      switch (fly) {
+#define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+        NBDT_CASE(1) NBDT_CASE(2) NBDT_CASE(3) NBDT_CASE(4) NBDT_CASE(5) NBDT_CASE(6)
+#undef NBDT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= P2(u): K chunk 1 -> registers =================
+    read_chunk(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= M(u): 2 x 3 x WM MFMAs; their shadow prepares P1(u+1) =================
+    __builtin_amdgcn_s_setprio(1);
+    prepare(slot_n);
+    stage_off(s_begin + u + 1 + PD, g_next, x_next);       // (past the end: computed, never used)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+          acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kk][a], x_frag(kk, t), acc[t][a], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < KK * 3 * WM; ++i) {                // one MFMA, one VALU / SALU in its shadow
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+v"(xa[kk][0]), "+v"(xa[kk][1]), "+v"(xa[kk][2]));
+    asm volatile("" : "+v"(ga[0]), "+v"(ga[1]));
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    slot_n = slot_n + 1 == NSLOT ? 0 : slot_n + 1;
+    slot_d = slot_d + 1 == NSLOT ? 0 : slot_d + 1;
+  }
+  for (int i = grp; i < 2; ++i) __builtin_amdgcn_s_barrier();     // this group's idle slots at the end
+  // ---- epilogue: acc[t][a][r]: tap 3 grp + t; co = co0 + (wm*WM + a)*16 + 4*g4 + r ; ci = ci0 + wn*16 + t16
+  const int ci = ci0 + wn * 16 + t16;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int w_tap = d.w_tap[3 * grp + t];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
+        atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
+      }
+  }
+}
+
 namespace nbdt {
 
 static bool stage_geometry(const nbdt_wgrad_desc* d, int ks, int max_hp, WgradTapsParams* p);
@@ -710,13 +1276,19 @@ static int cout_tiles_wm(int cout) {
   return mt % 5 == 0 ? 5 : (mt % 4 == 0 ? 4 : (mt % 2 == 0 ? 2 : 1));
 }
 
-template <int WM, bool PP>
+// KIND 0: conv_wgrad_taps_kernel (4 waves, 2 blocks per CU), 1: conv_wgrad_pp_kernel (8 waves, two wave groups),
+// 2: conv_wgrad_pp3_kernel (12 waves, three wave groups), 3: conv_wgrad_ks_kernel (8 waves, groups split the pixels).
+// 1, 2 and 3 share the stage image, the split and the LDS size.
+template <int WM, int KIND>
 static int launch_taps(WgradTapsParams& p, hipStream_t st) {
+  constexpr bool PP = KIND != 0;
   split_items(p, WM, PP);
   const size_t shmem = PP ? (size_t)5 * (64 * 64 * WM + 144 * 64) : (size_t)NSTAGE * ((32 * WM / 8) * 512 + x_bytes(4));
-  const void* fn = PP ? reinterpret_cast<const void*>(&conv_wgrad_pp_kernel<WM>)
-                      : reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, 4>);
-  static DeviceAttr site;     // one per (WM, PP) instantiation
+  const void* fn = KIND == 3 ? reinterpret_cast<const void*>(&conv_wgrad_ks_kernel<WM>)
+                   : KIND == 2 ? reinterpret_cast<const void*>(&conv_wgrad_pp3_kernel<WM>)
+                   : KIND == 1 ? reinterpret_cast<const void*>(&conv_wgrad_pp_kernel<WM>)
+                               : reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<WM, 4>);
+  static DeviceAttr site;     // one per (WM, KIND) instantiation
   if (site.need(shmem)) {
     NBDT_ATTR_CHECK(site, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     site.done(shmem);
@@ -732,8 +1304,9 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
     p.dw_split_stride = (long long)dw_elems;
   }
   void* args[] = {(void*)&p};
-  NBDT_HIP_CHECK(hipLaunchKernel(fn, dim3(p.per_xcd * 8), dim3(PP ? 512 : 256), args, shmem, st));
-  g_last_wgrad = PP ? "conv_wgrad_pp_kernel" : "conv_wgrad_taps_kernel";
+  NBDT_HIP_CHECK(hipLaunchKernel(fn, dim3(p.per_xcd * 8), dim3(KIND == 2 ? 768 : (KIND == 0 ? 256 : 512)), args, shmem, st));
+  g_last_wgrad = KIND == 3 ? "conv_wgrad_ks_kernel" : KIND == 2 ? "conv_wgrad_pp3_kernel"
+                           : (KIND == 1 ? "conv_wgrad_pp_kernel" : "conv_wgrad_taps_kernel");
   if (p.dw != dw) return det_fold(st, p.dw, p.splits, dw_elems, dw);
   return NBDT_OK;
 }
@@ -745,9 +1318,10 @@ static bool pp_fits_shape(const nbdt_wgrad_desc* d) {
   return d->gw % 8 == 0 && stage_geometry(d, 64, 144, nullptr) && (long long)d->B * d->x_bs * 2 < (1ll << 32) &&
          (long long)d->B * d->g_bs * 2 < (1ll << 32);
 }
+constexpr bool kKsDefault = true;        // the K-split kernel won its A/B (profiles/r05_wgrad_ksplit_ab.txt: 2-7 % by shape)
 static bool takes_pp(const nbdt_wgrad_desc* d, bool pp_fits) {
   const long long M = (long long)d->B * d->gh * d->gw;
-  return pp_fits && (d->variant == 2 || (d->variant != 3 && M / 64 >= 32 * 8));
+  return pp_fits && (d->variant == 2 || d->variant == 4 || d->variant == 5 || (d->variant != 3 && M / 64 >= 32 * 8));
 }
 
 int wgrad_taps_blocks(const nbdt_wgrad_desc* d) {
@@ -767,20 +1341,36 @@ int wgrad_taps(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* d
   p.dw = dw;
   const int mt = d->cout / 32;
   const bool pp_fits = pp_fits_shape(d);
-  NBDT_REQUIRE(!(d->variant == 2 && !pp_fits), "variant 2 (8-wave weight-gradient kernel): shape does not fit it");
+  NBDT_REQUIRE(!((d->variant == 2 || d->variant == 4 || d->variant == 5) && !pp_fits),
+               "variant 2 / 4 / 5 (8- / 12-wave / K-split weight-gradient kernel): shape does not fit it");
   const bool pp = takes_pp(d, pp_fits);
   if (pp) {
     stage_geometry(d, 64, 144, &p);
-    if (mt % 5 == 0) return launch_taps<5, true>(p, st);
-    if (mt % 4 == 0) return launch_taps<4, true>(p, st);
-    if (mt % 2 == 0) return launch_taps<2, true>(p, st);
-    return launch_taps<1, true>(p, st);
+    // which kernel: variant 2 / 4 / 5 force one (tap-split 8 waves / 12 waves / K-split); 0 = kKsDefault decides
+    const bool ksplit = d->variant == 5 || (d->variant == 0 && kKsDefault);
+    if (ksplit) {
+      if (mt % 5 == 0) return launch_taps<5, 3>(p, st);
+      if (mt % 4 == 0) return launch_taps<4, 3>(p, st);
+      if (mt % 2 == 0) return launch_taps<2, 3>(p, st);
+      return launch_taps<1, 3>(p, st);
+    }
+    const bool three = d->variant == 4;
+    if (three) {
+      if (mt % 5 == 0) return launch_taps<5, 2>(p, st);
+      if (mt % 4 == 0) return launch_taps<4, 2>(p, st);
+      if (mt % 2 == 0) return launch_taps<2, 2>(p, st);
+      return launch_taps<1, 2>(p, st);
+    }
+    if (mt % 5 == 0) return launch_taps<5, 1>(p, st);
+    if (mt % 4 == 0) return launch_taps<4, 1>(p, st);
+    if (mt % 2 == 0) return launch_taps<2, 1>(p, st);
+    return launch_taps<1, 1>(p, st);
   }
   stage_geometry(d, 32, 128, &p);
-  if (mt % 5 == 0) return launch_taps<5, false>(p, st);
-  if (mt % 4 == 0) return launch_taps<4, false>(p, st);
-  if (mt % 2 == 0) return launch_taps<2, false>(p, st);
-  return launch_taps<1, false>(p, st);
+  if (mt % 5 == 0) return launch_taps<5, 0>(p, st);
+  if (mt % 4 == 0) return launch_taps<4, 0>(p, st);
+  if (mt % 2 == 0) return launch_taps<2, 0>(p, st);
+  return launch_taps<1, 0>(p, st);
 }
 
 }  // namespace nbdt

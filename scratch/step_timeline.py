@@ -30,7 +30,7 @@ busy += cur_e - cur_s
 print(f"GPU idle (no kernel on any queue) {1e-3 * ((t1 - t0) - busy):8.1f} us")
 # forward: time by kernel family between t0 and loss
 def fam(n):
-    for k in ("conv3x3_pp_kernel", "conv_igemm_dma_kernel", "conv_wgrad_pp_kernel", "conv_wgrad_dma_kernel", "bn_apply_kernel", "bn_fold_partials",
+    for k in ("conv3x3_pp_kernel", "conv_igemm_dma_kernel", "conv_wgrad_ks_kernel", "conv_wgrad_pp_kernel", "conv_wgrad_dma_kernel", "bn_apply_kernel", "bn_fold_partials",
               "bn_bwd_reduce_cus", "bn_bwd_apply_cus", "bn_bwd_finalize", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "weight_", "sgd", "Fill"):
         if k in n:
             return k

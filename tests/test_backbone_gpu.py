@@ -382,7 +382,7 @@ def test_weight_gradient_with_a_cu_budget(B, H, W, C, expect):
         assert ops.conv_wgrad_blocks(d, budget) == blocks
         dw = torch.zeros(C * 9 * C, device=DEV)
         ops.conv_wgrad(d, xp, gp, dw, cu_budget=budget)
-        assert ops.last_wgrad_kernel() == "conv_wgrad_pp_kernel"
+        assert ops.last_wgrad_kernel() == "conv_wgrad_ks_kernel"
         if ref is None:
             ref = dw
         else:
@@ -873,7 +873,7 @@ def test_bench_shape_conv_forward_dgrad_wgrad(B, H, W, C):
     # weight gradient (all-taps kernel at its production tile count)
     dw = torch.zeros(C, 9, C, dtype=torch.float32, device=DEV)
     ops.conv_wgrad(ops.conv_wgrad_desc(B, H, W, C, C, 3, 1), xp, gp, dw)
-    assert ops.last_wgrad_kernel() == "conv_wgrad_pp_kernel"
+    assert ops.last_wgrad_kernel() == "conv_wgrad_ks_kernel"
     gw_ref = wref.grad.permute(0, 2, 3, 1).reshape(C, 9, C)
     np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), rtol=2e-3, atol=2e-3 * gw_ref.abs().mean().item())
 
@@ -881,9 +881,9 @@ def test_bench_shape_conv_forward_dgrad_wgrad(B, H, W, C):
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 32, 32, 32, 160), (3, 16, 16, 64, 64), (9, 8, 8, 160, 320),
                                             (1, 32, 32, 96, 32), (5, 16, 16, 160, 160), (1, 8, 8, 64, 128)])
 def test_weight_gradient_kernel_variants(B, H, W, cin, cout):
-    """The 8-wave two-pipeline weight-gradient kernel (variant 2: two wave groups on stages of opposite parity, odd
-    and tiny stage counts included) and the 4-wave kernel (variant 3) against fp32 PyTorch on the same bf16 inputs,
-    with += semantics."""
+    """The 8-wave weight-gradient kernel (variant 2: two wave groups one barrier apart on the same LDS stage; odd and
+    tiny stage counts included), the 12-wave one (variant 4: three groups, one kernel row each) and the 4-wave kernel
+    (variant 3) against fp32 PyTorch on the same bf16 inputs, with += semantics."""
     xf, xp = _rand_act(B, H, W, cin, seed=91)
     gf, gp = _rand_act(B, H, W, cout, seed=92)
     xt = xf.permute(0, 3, 1, 2)
@@ -891,7 +891,8 @@ def test_weight_gradient_kernel_variants(B, H, W, cin, cout):
     F.conv2d(xt, wref, padding=1).backward(gf.permute(0, 3, 1, 2))
     gw_ref = wref.grad.permute(0, 2, 3, 1).reshape(cout, 9, cin)
     tol = dict(rtol=2e-3, atol=2e-3 * gw_ref.abs().mean().item())
-    for variant, name in ((2, "conv_wgrad_pp_kernel"), (3, "conv_wgrad_taps_kernel")):
+    for variant, name in ((2, "conv_wgrad_pp_kernel"), (5, "conv_wgrad_ks_kernel"), (4, "conv_wgrad_pp3_kernel"),
+                          (3, "conv_wgrad_taps_kernel")):
         d = ops.conv_wgrad_desc(B, H, W, cin, cout, 3, 1)
         d.variant = variant
         dw = torch.zeros(cout, 9, cin, dtype=torch.float32, device=DEV)

@@ -1234,9 +1234,15 @@ bool wgrad_taps_applicable(const nbdt_wgrad_desc* d) {
 static bool stage_geometry(const nbdt_wgrad_desc* d, int ks, int max_hp, WgradTapsParams* p) {
   const int gw = d->gw, gh = d->gh;
   if (!(gw % ks == 0 || ks % gw == 0)) return false;
-  const int rs = gw >= ks ? 1 : ks / gw;
+  int rs = gw >= ks ? 1 : ks / gw;
+  int cs = gw >= ks ? ks : gw;
+  if (ks == 64 && gw >= 64 && gw % 32 == 0 && gh % 2 == 0 && (rs + 2) * (cs + 2) > max_hp) {
+    // rows of 64+ pixels: a 64-pixel stage as one row has a 3 x 66 halo (198 slots, the 8-wave kernels hold 144); as a
+    // 2 x 32 rectangle -- two stages per 64 columns of a row pair -- it is 4 x 34 = 136 (round 5: ResNet18 at 64x64)
+    rs = 2;
+    cs = 32;
+  }
   if (gh % rs != 0) return false;
-  const int cs = gw >= ks ? ks : gw;
   if ((rs + 2) * (cs + 2) > max_hp) return false;
   const long long M = (long long)d->B * gh * gw;
   if (!p) return true;
@@ -1321,7 +1327,10 @@ static bool pp_fits_shape(const nbdt_wgrad_desc* d) {
 constexpr bool kKsDefault = true;        // the K-split kernel won its A/B (profiles/r05_wgrad_ksplit_ab.txt: 2-7 % by shape)
 static bool takes_pp(const nbdt_wgrad_desc* d, bool pp_fits) {
   const long long M = (long long)d->B * d->gh * d->gw;
-  return pp_fits && (d->variant == 2 || d->variant == 4 || d->variant == 5 || (d->variant != 3 && M / 64 >= 32 * 8));
+#ifndef NBDT_WPP_MIN_STAGES
+#define NBDT_WPP_MIN_STAGES 64             // (round 5: 256 -> 64, profiles/r05_other_configs_wgrad_ab.txt; A/B builds: other thresholds)
+#endif
+  return pp_fits && (d->variant == 2 || d->variant == 4 || d->variant == 5 || (d->variant != 3 && M / 64 >= NBDT_WPP_MIN_STAGES));
 }
 
 int wgrad_taps_blocks(const nbdt_wgrad_desc* d) {

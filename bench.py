@@ -45,7 +45,7 @@ PEAK_BF16_TFLOPS = 2500.0
 GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
 
 
-TRAFFIC_FILES = ("r04_final_hbm_traffic.json", "r03_split_hbm_traffic.json", "r02_final_hbm_traffic.json")   # newest first
+TRAFFIC_FILES = ("r05_final_hbm_traffic.json", "r04_final_hbm_traffic.json", "r03_split_hbm_traffic.json", "r02_final_hbm_traffic.json")   # newest first
 LOGIT_TOLERANCE = 3e-2          # max |logit error| / logit scale against the fp32 CPU port
 
 
@@ -53,7 +53,7 @@ def pmc_traffic(launches_per_step):
     """(bytes, source): HBM-side bytes per launch of the dominant kernel family -- launch-weighted over the
     forward / data-gradient kernels of the schedule this file times (plain-epilogue data gradients) -- from the
     newest committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs of this
-    same command with --no-overlap; scratch/r04_traffic.sh).  bench.py cannot collect PMC counters itself, so the
+    same command with --no-overlap; scratch/prof_bench.sh + scratch/traffic_report.py).  bench.py cannot collect PMC counters itself, so the
     number is only quoted when the file was recorded from THE SAME LAUNCHES: its "_meta" entry lists the implicit-GEMM
     kernels' launches per step by device kernel name, and `launches_per_step` is what this run's roofline pass
     counted (nbdt_debug_last_igemm after every launch).  Any difference -- a kernel renamed, added, re-routed --
@@ -287,25 +287,25 @@ def other_configs(dev, budget_s=0.6):
     out = []
     out.append(train_case("C1 ResNet18 + SoftTreeSupLoss, CIFAR10 (10 leaves)", E.ResNetEngine(10, device=dev),
                           "CIFAR10", "induced-ResNet18", 128, 32, 10, 1.0, gflop_img=GFLOP_RESNET18_32,
-                          profile="profiles/r04_c1_kernel_stats_one_stream.txt"))
+                          profile="profiles/r05_c1_kernel_stats_one_stream.txt"))
     out.append(train_case("C3 WideResNet28x10 + SoftTreeSupLoss, CIFAR100 (100 leaves): one GPU's 256-image share of "
                           "batch 1024 on 4 GPUs", E.WRNEngine(100, device=dev), "CIFAR100",
                           "induced-wrn28_10_cifar100", 256, 32, 100, 1.0, gflop_img=GFLOP_PER_IMG_TRAIN,
-                          profile="profiles/r04_c3_kernel_stats_one_stream.txt"))
+                          profile="profiles/r05_c3_kernel_stats_one_stream.txt"))
     eng = E.ResNetEngine(200, device=dev)
     out.append(train_case("C4 ResNet18 + SoftTreeSupLoss (tree-supervision weight 10), TinyImagenet200 64x64 (200 "
                           "leaves)", eng, "TinyImagenet200", "induced-ResNet18", 128, 64, 200, 10.0,
-                          gflop_img=GFLOP_RESNET18_64, profile="profiles/r04_c4_kernel_stats_one_stream.txt"))
+                          gflop_img=GFLOP_RESNET18_64, profile="profiles/r05_c4_kernel_stats_one_stream.txt"))
     rules = HardEmbeddedDecisionRules(tree=Tree("TinyImagenet200", hierarchy="induced-ResNet18"))
     x = torch.randn(128, 3, 64, 64, device=dev)
     dt, steps = timeit(lambda: rules.predict(eng.forward(x, training=False)))
     out.append(entry("C4 ResNet18 + HardNBDT (argmax path), TinyImagenet200 64x64", 128, dt, steps,
-                     gflop_img=GFLOP_RESNET18_64 / 3, profile="profiles/r04_c4inf_kernel_stats_one_stream.txt",
+                     gflop_img=GFLOP_RESNET18_64 / 3, profile="profiles/r05_c4inf_kernel_stats_one_stream.txt",
                      mode="inference: eval-mode backbone + hard decision rules"))
     del eng
     out.append(train_case("C5 EfficientNet-B0 + SoftTreeSupLoss, Imagenet1000 induced hierarchy (1000 leaves), 224x224",
                           EfficientNetEngine(1000, device=dev), "Imagenet1000", "induced-efficientnet_b7b", 128, 224,
-                          1000, 1.0, algorithmic_bytes=True, profile="profiles/r04_c5_kernel_stats_one_stream.txt"))
+                          1000, 1.0, algorithmic_bytes=True, profile="profiles/r05_c5_kernel_stats_one_stream.txt"))
     return out
 
 

@@ -17,7 +17,7 @@
 // nbdt_timing_build, which makes nbdt/_C.py refuse the library unless NBDT_ALLOW_TIMING_BUILD=1 -- a stray -D in a
 // product build is a compile error, not a silently wrong gradient.
 #if !defined(NBDT_TIMING_BUILD) &&                                                                                    \
-    (defined(NBDT_WPP_NO_EPI) || defined(NBDT_WKS_NO_EXCHANGE) || defined(NBDT_WPP_MIN_STAGES) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
+    (defined(NBDT_WPP_NO_EPI) || defined(NBDT_WKS_NO_EXCHANGE) || defined(NBDT_WKS_DMA_IN_M) || defined(NBDT_WPP_MIN_STAGES) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
      defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) || defined(NBDT_PP_NO_PAD) ||                    \
      defined(NBDT_HALO_NO_ACCUMULATE) || defined(NBDT_DW_TARGET) || defined(NBDT_DW_U) || defined(NBDT_HEAD_SPB) ||    \
      defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) ||                       \

@@ -854,12 +854,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ks_kernel(nbdt::WgradTapsPa
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#ifndef NBDT_WKS_DMA_IN_M
     if (u + PD < n_st) issue(slot_d, g_next, x_next);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ================= M(u): 9 x WM MFMAs; their shadow prepares L(u+1) =================
+#ifdef NBDT_WKS_DMA_IN_M      // experiment: this wave's pieces at the head of its MFMA segment instead of in the load segment
+    if (u + PD < n_st) issue(slot_d, g_next, x_next);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __builtin_amdgcn_s_setprio(1);
     prepare(slot_n);
     stage_off(s_begin + u + 1 + PD, g_next, x_next);       // (past the end: computed, never used)

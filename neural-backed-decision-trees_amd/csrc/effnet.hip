@@ -508,6 +508,71 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __r
   }
 }
 
+// Row-segment form of the STRIDE-2 data gradient (round 5).  dw_bwd_data_kernel above gathers, per input pixel, the
+// (K/2 .. K/2+1)^2 gradient pixels that reach it -- 6.25 16-byte loads per output at K = 5, each its own round trip -- and
+// took 2.2x the time of its bytes (97 us per launch on EfficientNet-B0's four stride-2 layers).  Here a thread owns 8
+// channels x TW consecutive pixels of one input row (TW even, so the segment starts on an even column): for each kernel row
+// r of the right parity it loads the TW/2 + K/2 + 1 gradient pixels of output row (hi + pad - r)/2 that reach the segment
+// ONCE and feeds each to the outputs it reaches (tap s = t + pad - 2 (wo - wi0/2), static after unrolling).  The gradient
+// tensor's zero border stands in for wo = -1 and wo = Wo.  Same sums in a different order than the gather kernel.
+template <int K, int TW>
+__global__ __launch_bounds__(kThreads) void dw_bwd_data_s2_row_kernel(const bf16_t* __restrict__ gy,
+                                                                      const float* __restrict__ w, MbGeom in, int Ho,
+                                                                      int Wo, int nseg, int PY, bf16_t* __restrict__ gx) {
+  // gradient columns wo = wi0/2 - 1 + j that reach the segment: tap s = t + PAD + 2 - 2 j in [0, K) for some t in [0, TW)
+  constexpr int PAD = K / 2, J0 = PAD == 1 ? 1 : 0, J1 = (TW + PAD + 1) / 2, SPAN = J1 - J0 + 1;
+  const int cx = threadIdx.x % in.c8, py = threadIdx.x / in.c8, b = blockIdx.y;
+  const int item = blockIdx.x * PY + py;
+  if (item >= in.H * nseg) return;
+  const int hi = item / nseg;
+  const int wi0 = (item - hi * nseg) * TW;
+  const int rowo = (Wo + 2) * in.C, imgo = (Ho + 2) * rowo;
+  float acc[TW][8];
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const int th = hi + PAD - r;
+    if (th < 0 || (th & 1) || (th >> 1) >= Ho) continue;
+    const int ho = th >> 1;
+    float wr[K][8];
+#pragma unroll
+    for (int sx = 0; sx < K; ++sx) {
+      const float4 w0 = *(const float4*)(w + (size_t)(r * K + sx) * in.C + cx * 8);
+      const float4 w1 = *(const float4*)(w + (size_t)(r * K + sx) * in.C + cx * 8 + 4);
+      wr[sx][0] = w0.x; wr[sx][1] = w0.y; wr[sx][2] = w0.z; wr[sx][3] = w0.w;
+      wr[sx][4] = w1.x; wr[sx][5] = w1.y; wr[sx][6] = w1.z; wr[sx][7] = w1.w;
+    }
+    const bf16_t* grow = gy + (size_t)b * imgo + (ho + 1) * rowo + in.C + cx * 8;     // + wo * C; wo = -1 and Wo: zero border
+    u32x4_t raw[SPAN];
+#pragma unroll
+    for (int j = 0; j < SPAN; ++j) {
+      const int wo = (wi0 >> 1) - 1 + J0 + j;
+      const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+      raw[j] = (wo >= -1 && wo <= Wo) ? *(const u32x4_t*)(grow + wo * in.C) : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < SPAN; ++j) {
+      float f[8];
+      unpack8(raw[j], f);
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        const int sx = t + PAD + 2 - 2 * (J0 + j);         // wi0 + t + pad - 2 wo, static after unrolling
+        if (sx >= 0 && sx < K) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[t][i] += f[i] * wr[sx][i];
+        }
+      }
+    }
+  }
+  bf16_t* xrow = gx + (size_t)b * in.img + (hi + 1) * in.row + in.C + cx * 8;
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+    if (wi0 + t < in.W) *(u32x4_t*)(xrow + (wi0 + t) * in.C) = pack8(acc[t]);
+}
+
 // dw[r*K+s][c] += sum_{b, output pixels} gy * x[ho*S + r - pad][wo*S + s - pad]
 // thread = (8-channel chunk, output row ho), blockIdx.z = kernel row r.  The thread walks its row left to
 // right keeping the K input pixels under the current output in registers (a sliding window: S new
@@ -933,6 +998,17 @@ extern "C" int nbdt_dwconv_bwd_data(const void* gy, const float* w, int32_t B, i
     const DwGeom d = dw_geom(B, H, W, C, k, 1, 4);
     return k == 3 ? launch_dw_row<3, 1, true>(gy, w, d, B, gx, nullptr, st)
                   : launch_dw_row<5, 1, true>(gy, w, d, B, gx, nullptr, st);
+  } else if (W % 4 == 0) {     // row-segment form: segments of 8 (or 4) input pixels
+    const int tw = W % 8 == 0 ? 8 : 4;
+    const int nseg = W / tw;
+    int PY = kThreads / in.c8;
+    if (PY < 1) PY = 1;
+    if (PY > H * nseg) PY = H * nseg;
+    const dim3 grid((H * nseg + PY - 1) / PY, B), blk(in.c8 * PY);
+#define NBDT_GO(K, TW) hipLaunchKernelGGL((dw_bwd_data_s2_row_kernel<K, TW>), grid, blk, 0, st, (const bf16_t*)gy, w, in, H / 2, W / 2, nseg, PY, (bf16_t*)gx)
+    if (k == 3) { if (tw == 8) NBDT_GO(3, 8); else NBDT_GO(3, 4); }
+    else        { if (tw == 8) NBDT_GO(5, 8); else NBDT_GO(5, 4); }
+#undef NBDT_GO
   } else {
     hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(in.slices, B), dim3(in.threads), 0, st, (const bf16_t*)gy, w, in,
                        H / stride, W / stride, k, stride, k / 2, 4, (bf16_t*)gx);

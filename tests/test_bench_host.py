@@ -63,17 +63,26 @@ def test_the_newest_file_wins_and_older_ones_are_fallbacks(bench, tmp_path, monk
     assert why2.endswith(bench.TRAFFIC_FILES[0]) and got2 == got + 40
 
 
-def test_committed_bench_line_is_consistent_with_its_committed_evidence(bench):
-    """profiles/r04_final_bench_line.json (what `python bench.py` printed on the GPU box) against the files it names:
-    the traffic it quotes is what pmc_traffic() derives from the committed PMC file for the launches that file records,
-    value x ms_per_step = the batch, every `frac` is achieved / peak, every other configuration names an existing profile."""
-    with open(os.path.join(ROOT, "profiles", "r04_final_bench_line.json")) as f:
+def test_committed_bench_line_is_consistent_with_its_committed_evidence(bench, monkeypatch):
+    """profiles/r05_final_bench_line.json (what `python bench.py` printed on the GPU box) against the files it names:
+    the traffic it quotes is what pmc_traffic() derives from the committed PMC file it names for the launches that file
+    records (the line of the final evidence run is printed BEFORE that run's own PMC passes, i.e. against the previous
+    round's file; the next run quotes the new one), value x ms_per_step = the batch, every `frac` is achieved / peak, the
+    measured ceilings are ordered achieved < attainable < mfma_stream < peak, every other configuration names an existing
+    profile."""
+    with open(os.path.join(ROOT, "profiles", "r05_final_bench_line.json")) as f:
         line = json.load(f)
-    with open(os.path.join(ROOT, "profiles", line["roofline"]["traffic_source"].split("/", 1)[1])) as f:
+    named = line["roofline"]["traffic_source"].split("/", 1)[1]
+    with open(os.path.join(ROOT, "profiles", named)) as f:
         meta = json.load(f)["_meta"]
+    monkeypatch.setattr(bench, "TRAFFIC_FILES", tuple(f for f in bench.TRAFFIC_FILES if f <= named))   # newest <= the named one
     got, src = bench.pmc_traffic(meta["igemm_launches_per_step"])
     assert src == line["roofline"]["traffic_source"]
-    assert abs(got - line["roofline"]["traffic"]) <= 0.02 * got      # (the line was printed against the previous pass's file)
+    assert abs(got - line["roofline"]["traffic"]) <= 0.02 * got
+    r = line["roofline"]
+    assert r["achieved"] < r["attainable"] < r["mfma_stream"] < r["peak"]
+    assert abs(r["frac_of_attainable"] - r["achieved"] / r["attainable"]) < 1e-3
+    assert abs(r["frac_of_mfma_stream"] - r["achieved"] / r["mfma_stream"]) < 1e-3
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 512) < 0.5
     for key in ("roofline", "roofline_wgrad"):
         r = line[key]

@@ -66,6 +66,16 @@ int nbdt_version(void);
  * nbdt_se_gate_bwd's parameter gradients) -- and the rules layer, which has no atomics. */
 int nbdt_set_deterministic(int32_t on);
 int nbdt_get_deterministic(void);
+/* Epilogue of the K-split weight-gradient kernel (nbdt_conv_wgrad on the 3x3 stride-1 shapes; process-wide, default 0).
+ * 0: fp32 atomics into dw.
+ * 1: each (pixel split, tile) block writes its partial sums with plain stores into that split's copy of dw in the
+ *    per-(device, stream) workspace (the one deterministic mode uses, same hipGraph rule: one eager launch first) and
+ *    a streaming pass adds the copies to dw in split order: the sum no longer depends on block timing.  The L2 retires
+ *    fp32 atomics at ~1.2 TB/s whatever their shape, so alone the launch is 4-8 % faster with the fold included; inside
+ *    the training step the fold's HBM traffic competes with the BatchNorm backward passes and the step time does not
+ *    move (profiles/r05_wgrad_store_epilogue_ab.txt).  Deterministic mode always takes this path for that kernel. */
+int nbdt_set_wgrad_store_epilogue(int32_t on);
+int nbdt_get_wgrad_store_epilogue(void);
 /* CUs (0..128, process-wide, default 0) the one-block-per-CU MFMA kernels leave free: the persistent forward / data-
  * gradient kernel launches 8 x (32 - ceil(n / 8)) blocks instead of 256 and the weight gradient is sized for at most
  * 256 - n.  For data-parallel training: RCCL's all-reduce kernels (one block per channel, NCCL_MAX_NCHANNELS of them)
@@ -179,12 +189,13 @@ typedef struct nbdt_conv_desc {
   int32_t in_bs, in_hs, in_ws, in_base;      /* element strides of the input pixel map */
   int32_t out_bs, out_hs, out_ws, out_base;  /* element strides of the output pixel map */
   int32_t accumulate;           /* 1: out += result (reads out) */
-  int32_t wide_tile;            /* dense 3x3 stride-1 launches: 0 / 1 = pick the kernel from the grid size (512-pixel
-                                   ping-pong tiles when they give >= 3/4 of the CUs a block, else 256-pixel tiles);
-                                   2 = force the 512-pixel kernel (error if the shape does not fit it), 3 = force the
-                                   256-pixel kernel, 4 = force the 512-pixel kernel with its padded LDS pitch (images
-                                   narrower than 32 pixels: bank-conflict-free halo reads, measured 1-2 % slower, so
-                                   never picked automatically).  2 / 3 / 4 exist for tests and A/B measurements. */
+  int32_t wide_tile;            /* dense 3x3 stride-1 launches with w_tiled: 0 / 1 = pick the tile from the grid size (the
+                                   8-wave ping-pong kernel on 512-pixel tiles when they give >= 3/4 of the CUs a block,
+                                   on 256-pixel half tiles when those fit the CUs in one round, else 512-pixel tiles);
+                                   2 = force 512-pixel tiles (error if the shape does not fit), 3 = force the 4-wave
+                                   256-pixel kernel, 4 = force 512-pixel tiles with the padded LDS pitch (images narrower
+                                   than 32 pixels: bank-conflict-free halo reads, measured 1-2 % slower, so never picked
+                                   automatically), 5 = force half tiles.  2 - 5 exist for tests and A/B measurements. */
   int32_t reserved;
   uint64_t w_tiled;             /* 0, or device pointer to the same weights pre-arranged by nbdt_weight_tile_batched
                                    (only dense 3x3 stride-1 launches with the identity tap map use it) */

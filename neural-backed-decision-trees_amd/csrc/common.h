@@ -85,6 +85,8 @@ struct DeviceAttr {
 // epilogue), whose order changes from run to run.  With the switch on, each of them adds into a zeroed library-owned
 // row per block / per pixel split instead -- one add per address -- and det_fold() sums the rows in index order.
 bool deterministic();
+// K-split weight gradient: plain stores into per-split copies + det_fold instead of fp32 atomics into dw (default off; deterministic mode: always)
+bool wgrad_store_epilogue();
 // CUs the one-block-per-CU MFMA kernels leave free (nbdt_set_reserved_cus): a collective's kernels (RCCL, one block per
 // channel) running beside the backward pass get them, instead of making persistent blocks wait for a CU they hold
 int reserved_cus();
@@ -191,7 +193,8 @@ struct HaloGeom {
   int a_instr;         // ceil(hp*4 / 64) wave-instructions per halo tile (wave w issues ids w, w+4, ..)
   int a_bytes;         // a_instr * 1024
   int blocks_per_img;  // gh / rb when ib == 1
-  int nwv;             // waves per block: 4 (256-pixel tile) or 8 (512-pixel tile)
+  int nwv;             // waves per block: 4 (256-pixel tile) or 8 (512-pixel tile, or 256-pixel half tile: mw == 1)
+  int mw;              // 32-pixel fragments per wave: 2, or 1 for the 8-wave kernel's half tile
   // LDS image of the halo (conv3x3_pp_kernel): rows of `lpitch` pixel slots.  pad = lpitch - hw2 is 0 (the halo is copied
   // as the one contiguous run it is in memory; a_instr covers hp pixels) or 2 for images narrower than 32 pixels: rows of
   // gw + 4 slots, the last two of each row unused, so that a 32-pixel fragment -- 2 or 4 image rows -- meets every bank

@@ -44,8 +44,8 @@ static int conv_igemm_impl(const nbdt_conv_desc* d, const void* in, const void* 
   nbdt::HaloGeom hg;
   if (nbdt::conv_halo_applicable(d, M, &hg))
     return nbdt::conv3x3_halo(d, hg, in, w, out, res, bn_scratch, bn, M, st);
-  NBDT_REQUIRE(d->wide_tile != 2 && d->wide_tile != 4,
-               "wide_tile = 2 / 4 (force the 512-pixel kernel [with the padded LDS pitch]): not a dense 3x3 stride-1 conv it fits");
+  NBDT_REQUIRE(d->wide_tile != 2 && d->wide_tile != 4 && d->wide_tile != 5,
+               "wide_tile = 2 / 4 / 5 (force 512-pixel tiles [with the padded LDS pitch] / half tiles): not a dense 3x3 stride-1 conv it fits");
   nbdt::g_last_igemm = "conv_igemm_dma_kernel";
   return nbdt::conv_igemm_dma(d, in, w, out, res, bn_scratch, bn, M, st);
 }

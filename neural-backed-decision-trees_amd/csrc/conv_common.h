@@ -96,8 +96,8 @@ struct EpiNoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `after_entry` runs once every wave of the block has passed the entry barrier (nobody reads the K ring any
 // more) and before the first LDS write: the persistent kernel issues the next tile's first LDS-DMA there.
-template <int NT, bool HAS_RES, int STATS, int NWV = 4, typename HOOK = EpiNoHook>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::ConvDmaParams& p,
+template <int NT, bool HAS_RES, int STATS, int NWV = 4, int MW = 2, typename HOOK = EpiNoHook>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][MW], const nbdt::ConvDmaParams& p,
                                               const EpiLds& lds, int m0, int n0, int m_blk, int wave, int lane,
                                               int tid, unsigned* epi_t = nullptr, HOOK after_entry = HOOK()) {
   NBDT_EPI_STAMP(0)
@@ -139,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   int* row_off = lds.row_off;              // element offset of each of the wave's 64 pixels
   float* blk_stats = lds.blk_stats;        // [2][BN]
   {
-    const int m = m0 + wave * 64 + lane;
+    const int m = m0 + wave * (32 * MW) + lane;     // (MW == 1: entries 32..63 belong to the next wave's pixels, never read)
     row_off[lane] = m < p.M ? pix_offset(m, d.gh, d.gw, d.out_bs, d.out_hs, d.out_ws, d.out_base) + n0 : -1;
     if ((STATS == 1 || STATS == 2) && !STATS_VIA_REGIONS) {
       for (int i = tid; i < 2 * BN; i += NTHR) blk_stats[i] = 0.f;
@@ -165,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
   }
 
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
+  for (int tm = 0; tm < MW; ++tm) {
     // Row offsets of this lane's ROW_ITERS rows, fetched from LDS in ONE batch.  (The first version read
     // row_off[] inside every loop below: each iteration was  ds_read -> wait -> [ds_read_b128 -> wait] -> store,
     // two LDS round trips per row, 12 rows, twice: 8 k cycles of a 72 k-cycle tile, measured with s_memtime.)
@@ -276,7 +276,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][2], const nbdt::
     NBDT_EPI_STAMP(3 + 2 * tm)
   }
   if (STATS == 1 || STATS == 2) {
-    constexpr int RPB = NWV / 4;
+    constexpr int RPB = NWV * MW / 8;      // 256-pixel rows of statistics per tile
     // one partial row per pixel tile, plain stores (no global atomics: 2048 blocks x 320 atomics cost more than the
     // separate statistics pass they replace); nbdt_bn_finalize folds the rows
     // (the fold kernels expect one row per 256 pixels: a 512-pixel tile fills row 2*m_blk and zeroes the next)

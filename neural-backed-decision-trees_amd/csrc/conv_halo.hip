@@ -122,12 +122,16 @@ __device__ __forceinline__ unsigned stamp() {
 // halo buffers -- 8x8x8-image tiles need 60 pieces per slice where taps 0..6 give 56 issue slots: waves 0-3 issue a second
 // piece at tap 0 -- and ~8 VALU per K step in the MFMA segment's shadow (a slot's row by multiply-shift, packed (slot, v)
 // fragment coordinates).  PAD = false is the kernel of rounds 2-4, instruction for instruction (32-wide images).
-template <int NT, bool HAS_RES, int STATS, int NWV, bool PAD>
+// MW = 32-pixel fragments per wave: 2 (64 pixels, tiles of 64 * NWV) or, 8 waves only, 1 -- the HALF tile of 256 pixels
+// for grids that give 512-pixel tiles to fewer than 3/4 of the CUs: the same two wave groups and segments, a wave's MFMA
+// segment is 2 * NT instead of 4 * NT instructions, every CU gets a tile (round 5).
+template <int NT, bool HAS_RES, int STATS, int NWV, bool PAD, int MW = 2>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaParams p, nbdt::HaloGeom hg) {
+  static_assert(MW == 2 || (MW == 1 && NWV == 8 && !PAD), "half tiles are the 8-wave kernel's");
   constexpr bool PP = NWV == 8;          // two wave groups alternating roles; NWV == 4: one group, two blocks per CU
   constexpr int APW = PP ? 1 : 2;        // halo pieces a wave may issue per step (taps 0..6: 7 * NWV * APW slots)
   constexpr int BN = 32 * NT;
-  constexpr int BMH = 64 * NWV;
+  constexpr int BMH = 32 * MW * NWV;
   constexpr int W_BYTES = BN * BK * 2;
   constexpr int W_INSTR = W_BYTES / 1024;
   constexpr int abl = NBDT_PP_ABLATE;
@@ -237,9 +241,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     }
   };
 
-  f32x16 acc[NT][2];
+  f32x16 acc[NT][MW];
   int frag_half;
-  int hp0[2];                      // halo index of this lane's two output pixels at tap (0,0)
+  int hp0[MW];                     // halo index of this lane's two output pixels at tap (0,0)
   unsigned w_rd0, w_rd1;           // LDS offsets of this lane's weight fragment rows (ks = 0, 1) in ring slot 0
   auto lane_constants = [&]() {
     int ln = lane;
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     const int frag_row = ln & 31;
     frag_half = ln >> 5;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int pl = wave * 64 + tm * 32 + frag_row;
+    for (int tm = 0; tm < MW; ++tm) {
+      const int pl = wave * (32 * MW) + tm * 32 + frag_row;
       const int per_img = hg.rb * d.gw;
       const int img = pl / per_img;
       const int rem = pl - img * per_img;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   typedef const __attribute__((address_space(3))) unsigned char* lds_cptr;   // 32-bit: reads stay ds_read_b128
   const lds_cptr smem3 = (lds_cptr)smem;
   struct Plan {
-    lds_cptr ra[2][2];        // LDS addresses of the pixel fragments [ks][tm]
+    lds_cptr ra[2][MW];       // LDS addresses of the pixel fragments [ks][tm]
     unsigned a_voff[APW];     // halo pieces: per-lane byte offsets
     int a_n;                  // ... and how many of them this wave issues in L(t)
     unsigned a_xoff;          // PAD: piece 56 + wave of the next slice, issued at tap 0 when the slice has more than
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   int a_pix0 = cur.base_pix + wave * 16;       // halo pixel of lane 0 of this wave's piece at tap 0 (per tile)
   auto prepare = [&](int tapn, int kcn) {     // plan of L(t) for t = (kcn, tapn); tapn is a literal after unrolling
     Plan q;
-    int h0 = hp0[0], h1 = hp0[1], lp = a_lane_pix, le = a_lane_el;
+    int h0 = hp0[0], h1 = hp0[MW - 1], lp = a_lane_pix, le = a_lane_el;
     asm volatile("" : "+v"(h0), "+v"(h1), "+v"(lp), "+v"(le));    // the address math stays in the segment that calls prepare()
     // tap offset: halo pixels; PAD: LDS slots | de-pitched pixels << 16 (rows of lpitch slots / lpitch - 4 pixels)
     const int toff = PAD ? (((tapn / 3) * lpitch + (tapn % 3)) | (((tapn / 3) * (lpitch - 4) + (tapn % 3)) << 16))
@@ -297,9 +301,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
       const unsigned o = frag_off(h0);
       q.ra[0][0] = smem3 + (abuf + o); q.ra[1][0] = smem3 + (abuf + (o ^ 32));
     }
-    {
+    if constexpr (MW == 2) {
       const unsigned o = frag_off(h1);
-      q.ra[0][1] = smem3 + (abuf + o); q.ra[1][1] = smem3 + (abuf + (o ^ 32));
+      q.ra[0][MW - 1] = smem3 + (abuf + o); q.ra[1][MW - 1] = smem3 + (abuf + (o ^ 32));
     }
     // up to APW pieces of the next halo slice per wave at taps 0..6: piece id = (tapn * APW + j) * NWV + wave
     q.a_n = 0;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 #pragma unroll
   for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < MW; ++tm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
   Plan plan = prepare(0, 0);
@@ -385,10 +389,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       // ================= L(t): fragments -> registers, this wave's DMA pieces =================
-      bf16x8 pf[2][2], wf[2][NT];
+      bf16x8 pf[2][MW], wf[2][NT];
       if (!(abl & 8)) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < MW; ++tm) {
           pf[0][tm] = *(const __attribute__((address_space(3))) bf16x8*)plan.ra[0][tm];
           pf[1][tm] = *(const __attribute__((address_space(3))) bf16x8*)plan.ra[1][tm];
         }
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm) { pf[ks][tm] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(pf[ks][tm])); }
+          for (int tm = 0; tm < MW; ++tm) { pf[ks][tm] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(pf[ks][tm])); }
 #pragma unroll
           for (int tn = 0; tn < NT; ++tn) { wf[ks][tn] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(wf[ks][tn])); }
         }
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 #pragma unroll
           for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < MW; ++tm)
               acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][tn], pf[ks][tm], acc[tn][tm], 0, 0, 0);
       }
 #ifdef NBDT_PP_DUMMY_VALU   // experiment: how much does extra VALU work in the MFMA shadow cost (an in-LDS BatchNorm pass)?
@@ -461,17 +465,18 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
       // one MFMA, then at most two of the preparation's VALU / SALU instructions in its shadow, 20 times
       if (!(NBDT_PP_SCHED & 2)) {
 #pragma unroll
-        for (int i = 0; i < 4 * NT; ++i) {
+        for (int i = 0; i < 2 * MW * NT; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
 #ifdef NBDT_PP_DUMMY_VALU
           __builtin_amdgcn_sched_group_barrier(0x002, 2 + NBDT_PP_DUMMY_VALU / 20 + 1, 0);   // VALU
 #else
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+          __builtin_amdgcn_sched_group_barrier(0x002, MW == 2 ? 2 : 3, 0);   // VALU (half tile: the same preparation, half the MFMAs)
 #endif
           __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
         }
       }
-      asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[0][1]), "+v"(plan.ra[1][0]), "+v"(plan.ra[1][1]), "+v"(plan.a_voff[0]));
+      asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[1][0]), "+v"(plan.a_voff[0]));
+      if (MW == 2) asm volatile("" : "+v"(plan.ra[0][MW - 1]), "+v"(plan.ra[1][MW - 1]));
       if (APW == 2) asm volatile("" : "+v"(plan.a_voff[APW - 1]));
       if (PAD && tap == 8) asm volatile("" : "+v"(plan.a_xoff));
       if (!(NBDT_PP_SCHED & 1)) __builtin_amdgcn_s_setprio(0);
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     if (early) issue_first(nxt);
   };
 #if NBDT_PP_TIMING == 2
-  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
+  conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
   if (tid == 0 && item < 8192) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -514,20 +519,20 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   tr_entry = stamp();
 #elif NBDT_PP_TIMING
   unsigned epi_t[8];
-  conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, epi_t, hook);
+  conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, epi_t, hook);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores acknowledged
   epi_t[6] = stamp();
   if (lane == 0 && item < 1024)
     for (int i = 0; i < 6; ++i) g_pp_epi[(item * 8 + wave) * 8 + i] = epi_t[i + 1] - epi_t[i];
 #else
-  if (!(abl & 32)) conv_epilogue<NT, HAS_RES, STATS, NWV>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
+  if (!(abl & 32)) conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
 #endif
   if (abl & 32) {   // timing experiment: no epilogue, but every accumulator stays live
     float sum = 0.f;
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < MW; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += acc[tn][tm][r];
     if (sum == 12345.f) p.out[0] = 0;
@@ -711,12 +716,14 @@ namespace nbdt {
 thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): which kernel the last launch used
 
 // KIND 0: conv3x3_pp_kernel<.., 8> (ping-pong), 1: conv3x3_pp_kernel<.., 4> (same segments, one group, two blocks
-// per CU), 2: conv3x3_halo_kernel (4 waves, plain weight layout)
+// per CU), 2: conv3x3_halo_kernel (4 waves, plain weight layout), 3: conv3x3_pp_kernel<.., 8, false, 1> (ping-pong,
+// 256-pixel half tiles)
 template <int NT, int KIND, bool PAD>
 static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
-  constexpr int NWV = KIND == 0 ? 8 : 4;
+  constexpr int NWV = (KIND == 0 || KIND == 3) ? 8 : 4;
+  constexpr int MW = KIND == 3 ? 1 : 2;
   constexpr int BN = 32 * NT;
-  constexpr int BMH = 64 * NWV;
+  constexpr int BMH = 32 * MW * NWV;
   p.n_blocks = p.d.cout / BN;
   p.m_blocks = (p.M + BMH - 1) / BMH;
   const int items = p.m_blocks * p.n_blocks;
@@ -729,7 +736,7 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   // buffer 1 and behind slot 1 -- a tile's first DMA is issued during the previous tile's epilogue.
   p.overlap = 0;
   int per_round = p.per_xcd;
-  if (KIND == 0) {
+  if (KIND == 0 || KIND == 3) {
     constexpr size_t REGION = 32 * (2 * BN + 16);
     const size_t in_a1 = std::min<size_t>(hg.a_bytes / REGION, NWV);
     const size_t need = 2 * (size_t)hg.a_bytes + 2 * (size_t)BN * BK * 2 + (NWV - in_a1) * REGION + NWV * 64 * 4 +
@@ -750,7 +757,7 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   const dim3 grid(per_round * 8), blk(64 * NWV);
 #define NBDT_KERNEL(R, S) \
   (KIND == 2 ? reinterpret_cast<const void*>(&conv3x3_halo_kernel<NT, R, S>) \
-             : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV, PAD>))
+             : reinterpret_cast<const void*>(&conv3x3_pp_kernel<NT, R, S, NWV, PAD, MW>))
   if (site.need(shmem)) {
 #define NBDT_ATTR(R, S) \
   NBDT_ATTR_CHECK(site, hipFuncSetAttribute(NBDT_KERNEL(R, S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
@@ -768,7 +775,7 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
 #undef NBDT_GO
 #undef NBDT_KERNEL
   g_last_igemm = KIND == 0 ? (PAD ? "conv3x3_pp_kernel/pad" : "conv3x3_pp_kernel")
-                           : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
+                           : KIND == 3 ? "conv3x3_pp_kernel/half" : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
   return NBDT_OK;
 }
 
@@ -811,6 +818,7 @@ static bool halo_geom_try(const nbdt_conv_desc* d, int tile, int nwv, bool pad, 
   hg->a_bytes = instr * 1024;
   hg->blocks_per_img = ib == 1 ? gh / rb : 1;
   hg->nwv = nwv;
+  hg->mw = tile == 32 * nwv ? 1 : 2;
   const int lds = 2 * hg->a_bytes + 3 * cout_tile(d->cout) * 32 * BK * 2;
   return lds <= (nwv == 4 ? 80 : 156) * 1024;   // 4 waves: 2 blocks per CU (80 KiB each); 8 waves: 1 block per CU
 }
@@ -824,10 +832,11 @@ static bool halo_geom_for(const nbdt_conv_desc* d, int tile, int nwv, bool pad, 
   return halo_geom_try(d, tile, nwv, false, hg);
 }
 
-// Dense 3x3 / stride-1 conv over a padded NHWC tensor?  Picks the 512-pixel ping-pong kernel when its grid gives
-// at least 3/4 of the 256 CUs a block (every WRN-28-10 layer at 512 images per GPU), else the 256-pixel kernel.
-// desc.wide_tile: 0/1 automatic, 2 force the 512-pixel kernel, 3 force the 256-pixel one, 4 force the 512-pixel kernel
-// with the padded LDS pitch (tests, A/B).
+// Dense 3x3 / stride-1 conv over a padded NHWC tensor?  With DMA-ordered weight tiles: the ping-pong kernel, on 512-pixel
+// tiles when they give at least 3/4 of the 256 CUs a block (every WRN-28-10 layer at 512 images per GPU), on 256-pixel
+// half tiles when those fit the CUs in one round; without them the 4-wave 256-pixel kernels.
+// desc.wide_tile: 0/1 automatic, 2 force 512-pixel tiles, 3 force the 4-wave 256-pixel kernel, 4 force 512-pixel tiles
+// with the padded LDS pitch, 5 force half tiles (tests, A/B).
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
 #ifdef NBDT_HALO_NO_ACCUMULATE          // A/B builds: accumulating data gradients on the first-generation kernel (rounds 1-3)
   if (d->accumulate) return false;
@@ -844,9 +853,21 @@ bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg) {
   // them gets the 256-pixel kernel, which also reads the plain [cout][tap][cin] layout)
   bool tiled = d->w_tiled != 0 && d->w_ntaps == 9;
   for (int t = 0; t < 9; ++t) tiled = tiled && d->w_tap[t] == t;
-  const long long tiles512 = ((long long)M + 511) / 512 * (d->cout / (32 * cout_tile(d->cout)));
+  const int n_blocks = d->cout / (32 * cout_tile(d->cout));
+  const long long tiles512 = ((long long)M + 511) / 512 * n_blocks;
+  const long long tiles256 = ((long long)M + 255) / 256 * n_blocks;
   if (d->wide_tile == 4) return tiled && halo_geom_for(d, 512, 8, true, hg);     // padded LDS pitch or an error
-  const bool want_wide = tiled && (d->wide_tile == 2 || (d->wide_tile != 3 && tiles512 >= 192));
+  if (d->wide_tile == 5) return tiled && halo_geom_for(d, 256, 8, false, hg);    // half tiles or an error
+  // Round 5: grids that give 512-pixel tiles to fewer than 3/4 of the CUs.  With at most one 256-pixel tile per CU the
+  // ping-pong kernel on HALF tiles beats the 4-wave kernel by 10-30 % (one 4-wave block per CU has no partner to overlap
+  // its load segment with: 149 -> 108 us at 256 x 8x8x640, profiles/r05_half_tile_ab.txt).  With more half tiles than CUs
+  // (a collective holds some: nbdt_set_reserved_cus) one round of 512-pixel tiles is shorter than two rounds of half
+  // tiles, and it never lost to the 4-wave kernel either (126 vs 149 us, same shape).
+  const int cus = 8 * (32 - (reserved_cus() + 7) / 8);
+  const bool pick = d->wide_tile != 2 && d->wide_tile != 3;
+  const bool want_half = tiled && pick && tiles512 < 192 && tiles256 <= cus;
+  if (want_half && halo_geom_for(d, 256, 8, false, hg)) return true;
+  const bool want_wide = tiled && d->wide_tile != 3;
   if (want_wide && halo_geom_for(d, 512, 8, false, hg)) return true;
   if (d->wide_tile == 2) return false;
   // (the 4-wave form keeps the contiguous halo image at every width: its two pieces per wave and step with the padded
@@ -887,7 +908,9 @@ int conv3x3_halo(const nbdt_conv_desc* d, const HaloGeom& hg, const void* in, co
   }
   // (a padded LDS pitch is only ever chosen together with DMA-ordered weights, i.e. for conv3x3_pp_kernel)
   if (hg.pad != 0 && p.w_tiled == nullptr) return nbdt::fail(NBDT_EINVAL, "%s%s", "padded halo pitch without tiled weights", "");
+  if (hg.mw == 1 && p.w_tiled == nullptr) return nbdt::fail(NBDT_EINVAL, "%s%s", "half tiles without tiled weights", "");
   if (hg.pad != 0 && hg.nwv != 8) return nbdt::fail(NBDT_EINVAL, "%s%s", "padded halo pitch is the 8-wave kernel's", "");
+  if (hg.nwv == 8 && hg.mw == 1) NBDT_DISPATCH(3, false)
   if (hg.nwv == 8) { if (hg.pad) NBDT_DISPATCH(0, true) else NBDT_DISPATCH(0, false) }
   if (p.w_tiled != nullptr) NBDT_DISPATCH(1, false)
   NBDT_DISPATCH(2, false)

@@ -66,7 +66,27 @@ __global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__
   dst[i] = s;
 }
 
+// four elements per thread (every weight tensor here is a multiple of 4 long and 16-byte aligned)
+__global__ __launch_bounds__(256) void det_fold4_kernel(const float4* __restrict__ rows, int nrows, size_t n4,
+                                                        float4* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = dst[i];
+  for (int r = 0; r < nrows; ++r) {
+    const float4 v = rows[(size_t)r * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  dst[i] = s;
+}
+
 int det_fold(hipStream_t st, const float* rows, int nrows, size_t n, float* dst) {
+  if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(det_fold4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)rows, nrows,
+                       n4, (float4*)dst);
+    NBDT_LAUNCH_CHECK();
+    return NBDT_OK;
+  }
   hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, nrows, n, dst);
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
@@ -78,6 +98,16 @@ extern "C" int nbdt_set_deterministic(int32_t on) {
   return NBDT_OK;
 }
 extern "C" int nbdt_get_deterministic(void) { return nbdt::deterministic() ? 1 : 0; }
+
+namespace nbdt {
+static std::atomic<int> g_wgrad_store{0};      // profiles/r05_wgrad_store_epilogue_ab.txt: faster alone, no gain inside the step
+bool wgrad_store_epilogue() { return g_wgrad_store.load(std::memory_order_relaxed) != 0; }
+}  // namespace nbdt
+extern "C" int nbdt_set_wgrad_store_epilogue(int32_t on) {
+  nbdt::g_wgrad_store.store(on ? 1 : 0, std::memory_order_relaxed);
+  return NBDT_OK;
+}
+extern "C" int nbdt_get_wgrad_store_epilogue(void) { return nbdt::wgrad_store_epilogue() ? 1 : 0; }
 
 namespace nbdt {
 static std::atomic<int> g_reserved_cus{0};

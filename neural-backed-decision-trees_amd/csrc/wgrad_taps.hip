@@ -37,6 +37,8 @@ struct WgradTapsParams {
   int stages_per_split;
   int n_ci_blocks;       // cin / 32
   int splits, items, per_xcd;
+  int store;                   // K-split kernel: 1 = plain stores into this split's copy (every (split, tile) block writes
+                               // its whole tile, so the copies need no zeroing); det_fold sums the copies into dw
   int rs, cs;            // stage rectangle (rows x cols), rs*cs == 32
   int hw2;               // cs + 2
   int hp;                // (rs+2)*(cs+2) halo pixels (<= 128)
@@ -950,7 +952,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ks_kernel(nbdt::WgradTapsPa
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + (wm * WM + a) * 16 + 4 * g4 + r;
-        atomicAdd(p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci, acc[t][a][r]);
+        float* const dst = p.dw + (int64_t)split * p.dw_split_stride + ((int64_t)co * d.w_ntaps + w_tap) * d.cin + ci;
+        if (p.store) *dst = acc[t][a][r];
+        else atomicAdd(dst, acc[t][a][r]);
       }
   }
 }
@@ -1308,10 +1312,15 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   float* const dw = p.dw;
   const size_t dw_elems = (size_t)p.d.cout * p.d.w_ntaps * p.d.cin;
   p.dw_split_stride = 0;
-  if (deterministic()) {
+  // K-split kernel: the L2 retires fp32 atomics at ~1.2 TB/s whatever their shape (profiles/r05_atomic_pattern_probe.txt),
+  // so its ~47 MB of partial sums per launch are written with plain stores into one copy of dw per pixel split and a
+  // streaming pass adds the copies to dw in split order (which also makes the result independent of block timing)
+  p.store = (KIND == 3 && (wgrad_store_epilogue() || deterministic())) ? 1 : 0;
+  if (p.store || deterministic()) {
     float* rows = det_rows(st, (size_t)p.splits * dw_elems);
-    if (!rows) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-split gradients", nbdt::det_rows_why());
-    NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
+    if (!rows) return nbdt::fail(NBDT_ENOMEM, "weight gradient: %s (%s)", "no workspace for the per-split gradients",
+                                 nbdt::det_rows_why());
+    if (!p.store) NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
     p.dw = rows;
     p.dw_split_stride = (long long)dw_elems;
   }

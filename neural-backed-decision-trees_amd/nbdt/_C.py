@@ -61,6 +61,8 @@ SIGNATURES = {
     "nbdt_device_count": (c_int, []),
     "nbdt_set_deterministic": (c_int, [c_int32]),
     "nbdt_get_deterministic": (c_int, []),
+    "nbdt_set_wgrad_store_epilogue": (c_int, [c_int32]),
+    "nbdt_get_wgrad_store_epilogue": (c_int, []),
     "nbdt_set_reserved_cus": (c_int, [c_int32]),
     "nbdt_probe_mfma_stream": (c_int, [c_int32, c_int32, _P, _P]),
     "nbdt_get_reserved_cus": (c_int, []),

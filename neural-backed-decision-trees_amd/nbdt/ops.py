@@ -32,6 +32,16 @@ def is_deterministic():
     return bool(lib().nbdt_get_deterministic())
 
 
+def set_wgrad_store_epilogue(on):
+    """K-split weight gradient: 1 = plain stores into per-split copies + a fold pass, 0 (default) = fp32 atomics into dw
+    (nbdt_set_wgrad_store_epilogue in include/nbdt_hip.h)."""
+    check(lib().nbdt_set_wgrad_store_epilogue(1 if on else 0))
+
+
+def wgrad_store_epilogue():
+    return bool(lib().nbdt_get_wgrad_store_epilogue())
+
+
 def set_reserved_cus(n):
     """CUs the one-block-per-CU MFMA kernels leave free for a collective's kernels (nbdt_set_reserved_cus)."""
     check(lib().nbdt_set_reserved_cus(int(n)))

@@ -679,6 +679,22 @@ def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout):
     else:
         with pytest.raises(Exception, match="wide_tile"):
             ops.conv_igemm(desc(4), xp, wb, out_pad)
+    # wide_tile = 5: the ping-pong kernel on HALF tiles (256 pixels, 32 per wave) for grids too small for 512-pixel tiles --
+    # same accumulation order, same bits, plain and with residual + statistics
+    out_half = ops.padded(B, H, W, cout, DEV)
+    ops.conv_igemm(desc(5), xp, wb, out_half)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel/half" and torch.equal(out_half, out_h)     # (out_h: still the plain forward)
+    _check_border_zero(out_half)
+    part_half = torch.full((((B * H * W + 255) // 256) * 2 * cout,), float("nan"), device=DEV)
+    part_ref = torch.full_like(part_half, float("nan"))
+    ops.conv_igemm(desc(5), xp, wb, out_half, residual=rp, bn_scratch=part_half)
+    ops.conv_igemm(desc(3), xp, wb, out_h, residual=rp, bn_scratch=part_ref)
+    assert torch.equal(out_half, out_h) and torch.isfinite(part_half).all()
+    m_a, r_a, m_b, r_b = (torch.empty(cout, device=DEV) for _ in range(4))
+    ops.bn_finalize(out_half, part_half, m_a, r_a)
+    ops.bn_finalize(out_h, part_ref, m_b, r_b)
+    np.testing.assert_allclose(m_a.cpu().numpy(), m_b.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r_a.cpu().numpy(), r_b.cpu().numpy(), rtol=1e-5)
     # residual + fused BatchNorm statistics epilogue
     n_part = ((B * H * W + 255) // 256) * 2 * cout
     part_pp = torch.full((n_part,), float("nan"), device=DEV)
@@ -712,7 +728,7 @@ def test_pingpong_kernel_dgrad_with_bn_backward_epilogue(B, H, W, cin, cout):
     mean, rstd = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
     ops.bn_stats(xp, scratch, mean, rstd)
     outs, sums = [], []
-    for mode, name in ((2, "conv3x3_pp_kernel"), (3, "conv3x3_pp_kernel/4w")):
+    for mode, name in ((2, "conv3x3_pp_kernel"), (3, "conv3x3_pp_kernel/4w"), (5, "conv3x3_pp_kernel/half")):
         (d,) = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 1)
         _force(d, mode).w_tiled = wdt.data_ptr()
         ga = ops.padded(B, H, W, cin, DEV)
@@ -727,9 +743,10 @@ def test_pingpong_kernel_dgrad_with_bn_backward_epilogue(B, H, W, cin, cout):
     gt = gp_ref = ops.interior(gp).float().cpu().permute(0, 3, 1, 2)
     gx_ref = F.conv_transpose2d(gt, w_oihw, padding=1).permute(0, 2, 3, 1)
     _close_bf16(ops.interior(outs[0]), gx_ref, "pp dgrad")
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
     scale = sums[1].abs().max().item()
     np.testing.assert_allclose(sums[0].cpu().numpy(), sums[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(sums[2].cpu().numpy(), sums[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
 
 
 BENCH_SHAPES = [
@@ -776,12 +793,18 @@ def test_pingpong_kernel_several_tiles_per_block(B, H, W, C):
         assert (k8, k4) == ("conv3x3_pp_kernel", "conv3x3_pp_kernel/4w")
         assert torch.equal(o8, o4)
         _check_border_zero(o8)
+        oh, ph, kh = fwd(5, residual, stats)         # half tiles: twice the items on the same persistent blocks
+        assert kh == "conv3x3_pp_kernel/half" and torch.equal(oh, o4)
         if stats:
+            mh, rh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+            ops.bn_finalize(oh, ph, mh, rh)
             m8, r8, m4, r4 = (torch.empty(C, device=DEV) for _ in range(4))
             ops.bn_finalize(o8, p8, m8, r8)
             ops.bn_finalize(o4, p4, m4, r4)
             np.testing.assert_allclose(m8.cpu().numpy(), m4.cpu().numpy(), rtol=1e-5, atol=1e-6)
             np.testing.assert_allclose(r8.cpu().numpy(), r4.cpu().numpy(), rtol=1e-5)
+            np.testing.assert_allclose(mh.cpu().numpy(), m4.cpu().numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(rh.cpu().numpy(), r4.cpu().numpy(), rtol=1e-5)
     # one spot check against fp32 arithmetic (a corner and a middle image), so that "same bits" is not "same bug"
     for b in (0, B // 2, B - 1):
         xi = ops.interior(xp)[b:b + 1].float().permute(0, 3, 1, 2)
@@ -794,7 +817,7 @@ def test_pingpong_kernel_several_tiles_per_block(B, H, W, C):
     mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     ops.bn_stats(xp, torch.zeros(ops.BN_SLOTS * 2 * C, device=DEV), mean, rstd)
     res = []
-    for mode in (2, 3):
+    for mode in (2, 3, 5):
         (dd,) = ops.conv_dgrad_descs(B, H, W, C, C, 3, 1)
         _force(dd, mode)
         dd.w_tiled = wdt.data_ptr()
@@ -806,7 +829,10 @@ def test_pingpong_kernel_several_tiles_per_block(B, H, W, C):
         res.append((gx, dg, db, ops.last_igemm_kernel()))
     assert (res[0][3], res[1][3]) == ("conv3x3_pp_kernel", "conv3x3_pp_kernel/4w")
     assert torch.equal(res[0][0], res[1][0])
+    assert res[2][3] == "conv3x3_pp_kernel/half" and torch.equal(res[2][0], res[1][0])
     scale = res[1][2].abs().mean().item() + res[1][1].abs().mean().item()
+    np.testing.assert_allclose(res[2][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(res[2][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
     np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
     np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
 
@@ -901,6 +927,23 @@ def test_weight_gradient_kernel_variants(B, H, W, cin, cout):
         np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), **tol)
         ops.conv_wgrad(d, xp, gp, dw)
         np.testing.assert_allclose(dw.cpu().numpy(), 2 * gw_ref.numpy(), rtol=2e-3, atol=2 * tol["atol"])
+    # the K-split kernel's other epilogue: plain stores into one copy of dw per pixel split + a fold in split order
+    # (nbdt_set_wgrad_store_epilogue) -- the same sums, += semantics, and the same bits twice (no atomics left)
+    assert not ops.wgrad_store_epilogue()
+    ops.set_wgrad_store_epilogue(True)
+    try:
+        d = ops.conv_wgrad_desc(B, H, W, cin, cout, 3, 1)
+        d.variant = 5
+        runs = []
+        for _ in range(2):
+            dw = torch.full((cout, 9, cin), 0.5, dtype=torch.float32, device=DEV)
+            ops.conv_wgrad(d, xp, gp, dw)
+            assert ops.last_wgrad_kernel() == "conv_wgrad_ks_kernel"
+            runs.append(dw)
+        np.testing.assert_allclose(runs[0].cpu().numpy() - 0.5, gw_ref.numpy(), rtol=2e-3, atol=tol["atol"] + 1e-6)
+        assert torch.equal(runs[0], runs[1])
+    finally:
+        ops.set_wgrad_store_epilogue(False)
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 160, 320), (6, 16, 16, 320, 640), (64, 32, 32, 160, 320),

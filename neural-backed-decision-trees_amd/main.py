@@ -89,16 +89,7 @@ def build_parser():
     p.add_argument("--hierarchy")
     p.add_argument("--path-graph")
     p.add_argument("--path-wnids")
-    # nbdt/loss.py:27-61
-    p.add_argument("--xent-weight", "--xw", type=float)
-    p.add_argument("--xent-weight-end", "--xwe", type=float)
-    p.add_argument("--xent-weight-power", "--xwp", type=float)
-    p.add_argument("--tree-supervision-weight", "--tsw", type=float, default=1)
-    p.add_argument("--tree-supervision-weight-end", "--tswe", type=float)
-    p.add_argument("--tree-supervision-weight-power", "--tswp", type=float)
-    p.add_argument("--tree-start-epochs", "--tse", type=int)            # SoftTreeLoss, nbdt/loss.py:62-80
-    p.add_argument("--tree-update-every-epochs", "--tueve", type=int)
-    p.add_argument("--tree-update-end-epochs", "--tuene", type=int)
+    losses.add_arguments(p)      # --xent-weight* / --tree-supervision-weight* / --tree-*-epochs (reference nbdt/loss.py:27-80)
     # data source (see module docstring)
     p.add_argument("--data-file", help="torch.save'd dict: train_x, train_y, test_x, test_y")
     p.add_argument("--synthetic", type=int, default=0, help="number of synthetic training samples")

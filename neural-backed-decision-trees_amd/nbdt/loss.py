@@ -19,10 +19,40 @@ import torch.nn as nn
 from nbdt import _C
 from nbdt.model import HardEmbeddedDecisionRules, SoftEmbeddedDecisionRules
 from nbdt.tree import Tree
+from nbdt.utils import dataset_to_default_path_graph, dataset_to_default_path_wnids, hierarchy_to_path_graph
 
 __all__ = names = ("HardTreeSupLoss", "SoftTreeSupLoss", "SoftTreeLoss", "CrossEntropyLoss")
 
 CrossEntropyLoss = nn.CrossEntropyLoss
+
+
+def add_arguments(parser):
+    """The loss flags of the training driver (reference nbdt/loss.py:27-80): schedule end points / powers of the two
+    weights, and SoftTreeLoss's hierarchy re-induction epochs."""
+    for flags, kw in (
+            (("--xent-weight", "--xw"), dict(type=float, help="weight of the cross-entropy term")),
+            (("--xent-weight-end", "--xwe"), dict(type=float, help="its value at the end of training (default: constant)")),
+            (("--xent-weight-power", "--xwp"), dict(type=float, help="training progress is raised to this power")),
+            (("--tree-supervision-weight", "--tsw"), dict(type=float, default=1, help="weight of the tree-supervision term")),
+            (("--tree-supervision-weight-end", "--tswe"), dict(type=float, help="its value at the end of training (default: constant)")),
+            (("--tree-supervision-weight-power", "--tswp"), dict(type=float, help="> 1 approaches the end value later, < 1 sooner")),
+            (("--tree-start-epochs", "--tse"), dict(type=int, help="SoftTreeLoss: first epoch with a tree term (the hierarchy is induced there)")),
+            (("--tree-update-end-epochs", "--tuene"), dict(type=int, help="SoftTreeLoss: last epoch that re-induces the hierarchy")),
+            (("--tree-update-every-epochs", "--tueve"), dict(type=int, help="SoftTreeLoss: re-induce the hierarchy every this many epochs"))):
+        parser.add_argument(*flags, **kw)
+
+
+def set_default_values(args):
+    """Resolve --hierarchy / --path-graph / --path-wnids to files (reference nbdt/loss.py:83-91): a named hierarchy and an
+    explicit graph file exclude each other; without either the dataset's default induced hierarchy is used."""
+    if getattr(args, "hierarchy", None) and getattr(args, "path_graph", None):
+        raise AssertionError("Only one, between --hierarchy and --path-graph can be provided.")
+    if getattr(args, "hierarchy", None):
+        args.path_graph = hierarchy_to_path_graph(args.dataset, args.hierarchy)
+    if not getattr(args, "path_graph", None):
+        args.path_graph = dataset_to_default_path_graph(args.dataset)
+    if not getattr(args, "path_wnids", None):
+        args.path_wnids = dataset_to_default_path_wnids(args.dataset)
 
 
 def _is_plain_cross_entropy(criterion):

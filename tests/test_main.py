@@ -45,3 +45,30 @@ def test_flag_surface_matches_the_reference_recipes():
                      "--analysis SoftEmbeddedDecisionRules --resume --eval".split())
     assert a.tree_supervision_weight == 10 and a.loss == ["SoftTreeSupLoss"] and a.resume and a.eval
     assert a.hierarchy == "induced-wrn28_10_cifar100" and a.arch == "wrn28_10_cifar100"
+
+
+def test_loss_module_owns_its_flags_and_path_defaults():
+    """reference nbdt/loss.py:27-91: `add_arguments` defines the weight-schedule / re-induction flags (short aliases
+    included) and `set_default_values` resolves --hierarchy / --path-graph / --path-wnids; the driver's parser takes
+    its loss flags from there."""
+    import argparse
+    from nbdt import loss as losses
+    p = argparse.ArgumentParser()
+    losses.add_arguments(p)
+    a = p.parse_args(["--tsw", "10", "--tswe", "1", "--tswp", "2", "--xw", "0.5", "--xwe", "0", "--xwp", "3",
+                      "--tse", "5", "--tuene", "9", "--tueve", "2"])
+    assert (a.tree_supervision_weight, a.tree_supervision_weight_end, a.tree_supervision_weight_power) == (10, 1, 2)
+    assert (a.xent_weight, a.xent_weight_end, a.xent_weight_power) == (0.5, 0, 3)
+    assert (a.tree_start_epochs, a.tree_update_end_epochs, a.tree_update_every_epochs) == (5, 9, 2)
+    assert p.parse_args([]).tree_supervision_weight == 1
+    ns = argparse.Namespace(dataset="CIFAR10", hierarchy="induced-ResNet18", path_graph=None, path_wnids=None)
+    losses.set_default_values(ns)
+    assert ns.path_graph.endswith("graph-induced-ResNet18.json") and ns.path_wnids.endswith("wnids/CIFAR10.txt")
+    ns = argparse.Namespace(dataset="CIFAR10", hierarchy=None, path_graph=None, path_wnids=None)
+    losses.set_default_values(ns)
+    assert ns.path_graph.endswith("graph-induced.json")
+    import pytest
+    with pytest.raises(AssertionError, match="Only one"):
+        losses.set_default_values(argparse.Namespace(dataset="CIFAR10", hierarchy="induced", path_graph="x.json", path_wnids=None))
+    import main as driver
+    assert driver.build_parser().parse_args(["--tsw", "3"]).tree_supervision_weight == 3

@@ -7,6 +7,7 @@ using namespace nbdt;
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 using nbdt::u32x4_t;
 
@@ -28,6 +29,12 @@ struct ConvDmaParams {
   int M, n_blocks, m_blocks, per_xcd;
   int overlap;         // conv3x3_pp_kernel: the epilogue's LDS is laid out around the next tile's first slice
   int deterministic;   // nbdt_set_deterministic: the block's statistics are summed wave by wave, not with LDS atomics
+  // conv3x3_pp_kernel on half tiles, grids of at most half the CUs: `ksplit` blocks share an output tile, each takes a
+  // contiguous range of the input-channel slices, writes its accumulators to k_ws ([tile][split][float4 q][thread]) and
+  // takes a ticket; the block that draws the last one sums the ksplit partials in split order and runs the epilogue.
+  int ksplit;          // >= 1
+  float* k_ws;
+  unsigned* k_tickets; // [tiles], zero between launches (the last block of a tile resets its ticket)
 };
 }  // namespace nbdt
 

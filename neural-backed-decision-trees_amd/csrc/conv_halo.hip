@@ -24,6 +24,9 @@
 // K steps t = (kc, tap), tap fastest; per step a block consumes one 32-channel weight tile W(t) (ring of 3
 // slots) and a window of halo slice A(kc) (2 buffers).
 #include "conv_common.h"
+#include <cmath>
+#include <map>
+#include <mutex>
 
 #include <algorithm>
 
@@ -144,7 +147,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   // range with the XCD's other blocks, items  xcd * per_xcd + (b >> 3) + j * (gridDim / 8).
   const int bid = blockIdx.x;
   const int item_step = gridDim.x >> 3;
-  const int item_end = min(((bid & 7) + 1) * p.per_xcd, p.m_blocks * p.n_blocks);
+  constexpr bool KSPLIT = MW == 1;       // half tiles only: several blocks per output tile, each a range of K slices
+  const int ksplit = KSPLIT ? __builtin_amdgcn_readfirstlane(p.ksplit) : 1;
+  const int item_end = min(((bid & 7) + 1) * p.per_xcd, p.m_blocks * p.n_blocks * ksplit);
   int item = (bid & 7) * p.per_xcd + (bid >> 3);
   if (item >= item_end) return;
 
@@ -158,11 +163,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   const int cin = NBDT_PIN(d.cin);
   const int kchunks_w = cin >> 5;            // K chunks the weight tiles were laid out for
 #ifdef NBDT_PP_KFRAC5       // timing experiment (scratch/variants): only KFRAC5/5 of the K loop -- a main loop that much faster
-  const int kchunks = kchunks_w * NBDT_PP_KFRAC5 / 5;
+  const int kchunks_all = kchunks_w * NBDT_PP_KFRAC5 / 5;
 #else
-  const int kchunks = kchunks_w;
+  const int kchunks_all = kchunks_w;
 #endif
-  const int nk = 9 * kchunks;
+  int kchunks = kchunks_all;                 // K slices of the CURRENT tile (split K: this block's range of them)
+  int nk = 9 * kchunks;
   const int a_bytes = NBDT_PIN(hg.a_bytes);
   const int a_instr = NBDT_PIN(hg.a_instr);
   const int hw2 = NBDT_PIN(hg.hw2), himg = NBDT_PIN(hg.himg);
@@ -174,17 +180,24 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
                                          (unsigned)NBDT_PIN((unsigned)w_u));
   struct Tile {
     int item, m_blk, n_blk, m0, n0, base_pix;
-    const bf16_t* w_tiles;     // this cout tile's DMA-ordered weight tiles, step 0
+    int tile, ks, nkc;         // output tile, this block's K split and its number of slices
+    const bf16_t* w_tiles;     // this cout tile's DMA-ordered weight tiles, this block's first step
+    const bf16_t* in_k;        // input tensor at this block's first slice
   };
   auto tile_of = [&](int it) {
     Tile t;
     t.item = it;
-    t.m_blk = it / p.n_blocks;
-    t.n_blk = it - t.m_blk * p.n_blocks;
+    t.tile = it; t.ks = 0;
+    if (KSPLIT && ksplit > 1) { t.tile = it / ksplit; t.ks = it - t.tile * ksplit; }
+    t.m_blk = t.tile / p.n_blocks;
+    t.n_blk = t.tile - t.m_blk * p.n_blocks;
     t.m0 = t.m_blk * BMH;
     t.n0 = t.n_blk * BN;
     t.base_pix = NBDT_PIN(tile_origin(d, hg, t.m_blk).base_pix);
-    t.w_tiles = w_base + (size_t)t.n_blk * kchunks_w * 9 * (BN * 32);
+    const int kc0 = NBDT_PIN((t.ks * kchunks_all) / ksplit);
+    t.nkc = NBDT_PIN(((t.ks + 1) * kchunks_all) / ksplit) - kc0;
+    t.w_tiles = w_base + ((size_t)t.n_blk * kchunks_w + kc0) * 9 * (BN * 32);
+    t.in_k = in_base + kc0 * BK;
     return t;
   };
   Tile cur = tile_of(item);
@@ -209,16 +222,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     const int v = x - 4 * R;
     return (unsigned)(px * cin + ((lc ^ ((v >> 2) & 3)) << 3)) * 2u;
   };
-  auto issue_a_piece = [&](int base_pix, int buf, int kc, int id) {
+  auto issue_a_piece = [&](const bf16_t* src, int base_pix, int buf, int id) {      // src: the tensor at the slice to fetch
     int lp = a_lane_pix, le = a_lane_el;
     asm volatile("" : "+v"(lp), "+v"(le));            // keep this address math inside the step (registers)
     if (PAD) {
-      glds16_sf(in_base + kc * BK, pad_voff(lp + id * 16, le, base_pix), lds_base + buf * a_bytes + id * 1024);
+      glds16_sf(src, pad_voff(lp + id * 16, le, base_pix), lds_base + buf * a_bytes + id * 1024);
       return;
     }
     int px = lp + (base_pix + id * 16);
     px = px < last_pix ? px : last_pix;                // tail lanes / images past the batch re-read the last pixel
-    glds16_s(in_base + kc * BK, (unsigned)(px * cin + le) * 2u, lds_base + buf * a_bytes + id * 1024);
+    glds16_s(src, (unsigned)(px * cin + le) * 2u, lds_base + buf * a_bytes + id * 1024);
   };
   // W piece `id` = rows [16 id, 16 id + 16) of a weight tile.  The weights are the DMA-ordered tiles of
   // nbdt_weight_tile_batched: tile (n_blk, kc, tap) IS the swizzled LDS image, stored contiguously in step order,
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     if (abl & 1) return;
 #pragma unroll
     for (int k = 0; k < (PAD ? 8 : 7) * APW; ++k)
-      if (wave + NWV * k < a_instr) issue_a_piece(t.base_pix, 0, 0, wave + NWV * k);
+      if (wave + NWV * k < a_instr) issue_a_piece(t.in_k, t.base_pix, 0, wave + NWV * k);
     issue_w(t.w_tiles, 0, 0);
     issue_w(t.w_tiles, 1, 1);
   };
@@ -358,7 +371,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   for (;;) {   // ======================================= one output tile =======================================
   const int m_blk = cur.m_blk, m0 = cur.m0, n0 = cur.n0;
   const bf16_t* w_tiles = cur.w_tiles;
+  const bf16_t* in_k = cur.in_k;
   item = cur.item;
+  if (KSPLIT) { kchunks = cur.nkc; nk = 9 * kchunks; }
   lane_constants();
   a_pix0 = cur.base_pix + wave * 16;
 #pragma unroll
@@ -423,10 +438,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 #pragma unroll
           for (int j = 0; j < APW; ++j)
             if (j < plan.a_n)
-              glds16_s(in_base + (kc + 1) * BK, plan.a_voff[j],
+              glds16_s(in_k + (kc + 1) * BK, plan.a_voff[j],
                        lds_base + ((kc + 1) & 1) * a_bytes + ((tap * APW + j) * NWV + wave) * 1024);
           if (PAD && tap == 0 && plan.a_x)
-            glds16_sf(in_base + (kc + 1) * BK, plan.a_xoff,
+            glds16_sf(in_k + (kc + 1) * BK, plan.a_xoff,
                       lds_base + ((kc + 1) & 1) * a_bytes + (7 * APW * NWV + wave) * 1024);
         }
       }
@@ -507,6 +522,69 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   auto hook = [&]() {
     if (early) issue_first(nxt);
   };
+  bool run_epilogue = true;
+  if (KSPLIT && ksplit > 1) {
+    // ---- split K: park this block's accumulators, take a ticket; the last block of the tile sums all ksplit partials in
+    // split order (its own included: the result does not depend on who came last) and runs the epilogue.  Partials cross
+    // XCDs, whose L2s are not coherent with each other: they are written and read with agent-scope (sc1) accesses, which
+    // go through the L2 to memory.  (Not fences: __threadfence() is a write-back + invalidate of the WHOLE L2 per wave --
+    // 256 blocks of them made a 39 us launch take 226 us.)
+    constexpr int NQ = NT * MW * 4;                     // float4s per thread
+    // (one running pointer, opaque to the optimiser: NQ hoisted 64-bit addresses would cost the K loop its registers)
+    f32x4* mine = (f32x4*)p.k_ws + ((size_t)cur.tile * ksplit + cur.ks) * NQ * (64 * NWV) + tid;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < MW; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = f32x4{acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine), "v"(v) : "memory");
+          mine += 64 * NWV;
+          asm volatile("" : "+v"(mine));
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's partials have reached memory
+    __builtin_amdgcn_s_barrier();                       // ... every wave's have; every wave is done with the K ring
+    unsigned ticket = 0;
+    if (tid == 0) ticket = atomicAdd(p.k_tickets + cur.tile, 1u);
+    // (thread 0 sits in wave 0: the other waves get the ticket through LDS -- the K ring is free after the barrier above)
+    volatile unsigned* tk = (volatile unsigned*)(smem + 2 * a_bytes);
+    if (tid == 0) *tk = ticket;
+    __syncthreads();
+    ticket = *tk;
+    __syncthreads();                                    // read before the next tile's first DMA may land there
+    run_epilogue = ticket == (unsigned)(ksplit - 1);
+    if (run_epilogue) {
+      if (tid == 0) p.k_tickets[cur.tile] = 0;          // ready for the next launch
+      // (agent-scope relaxed loads, 8 bytes each: the compiler keeps a whole split's worth in flight)
+      const unsigned long long* all = (const unsigned long long*)((const f32x4*)p.k_ws + (size_t)cur.tile * ksplit * NQ * (64 * NWV) + tid);
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < MW; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
+      for (int s2 = 0; s2 < ksplit; ++s2) {
+        const unsigned long long* src = all + (size_t)s2 * NQ * (64 * NWV) * 2;
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < MW; ++tm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              acc[tn][tm][4 * q] += __uint_as_float((unsigned)lo);
+              acc[tn][tm][4 * q + 1] += __uint_as_float((unsigned)(lo >> 32));
+              acc[tn][tm][4 * q + 2] += __uint_as_float((unsigned)hi);
+              acc[tn][tm][4 * q + 3] += __uint_as_float((unsigned)(hi >> 32));
+              src += 64 * NWV * 2;
+            }
+      }
+    } else {
+      hook();                                           // (what the epilogue would have done after its entry barrier)
+    }
+  }
 #if NBDT_PP_TIMING == 2
   conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
   if (tid == 0 && item < 8192) {
@@ -525,7 +603,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
   if (lane == 0 && item < 1024)
     for (int i = 0; i < 6; ++i) g_pp_epi[(item * 8 + wave) * 8 + i] = epi_t[i + 1] - epi_t[i];
 #else
-  if (!(abl & 32)) conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
+  if (!(abl & 32) && run_epilogue)
+    conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, p, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
 #endif
   if (abl & 32) {   // timing experiment: no epilogue, but every accumulator stays live
     float sum = 0.f;
@@ -713,6 +792,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(nbdt::ConvDmaParam
 
 namespace nbdt {
 
+// tickets of the split-K tiles: one zeroed array per (device, stream), like the det_rows workspace; the last block of a
+// tile puts its ticket back to 0, so the array is all zero between launches
+constexpr int kMaxSplitTiles = 4096;
+static std::mutex g_ticket_mutex;
+static std::map<std::pair<int, hipStream_t>, unsigned*> g_tickets;
+static unsigned* split_tickets(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ticket_mutex);
+  unsigned*& t = g_tickets[std::make_pair(dev, st)];
+  if (t) return t;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  unsigned* q = nullptr;
+  if (hipMalloc((void**)&q, kMaxSplitTiles * sizeof(unsigned)) != hipSuccess) return nullptr;
+  if (hipMemset(q, 0, kMaxSplitTiles * sizeof(unsigned)) != hipSuccess) { (void)hipFree(q); return nullptr; }
+  t = q;
+  return t;
+}
+
 thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): which kernel the last launch used
 
 // KIND 0: conv3x3_pp_kernel<.., 8> (ping-pong), 1: conv3x3_pp_kernel<.., 4> (same segments, one group, two blocks
@@ -726,7 +825,36 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   constexpr int BMH = 32 * MW * NWV;
   p.n_blocks = p.d.cout / BN;
   p.m_blocks = (p.M + BMH - 1) / BMH;
-  const int items = p.m_blocks * p.n_blocks;
+  int items = p.m_blocks * p.n_blocks;
+  p.ksplit = 1; p.k_ws = nullptr; p.k_tickets = nullptr;
+  if (KIND == 3) {
+    // Half tiles on at most half the CUs with a LONG K loop (ResNet18's last stage at batch 128: 32 tiles of 144 K steps):
+    // split K.  A block's time is ~ b * steps / S for the loop plus ~2.8 us per split for the exchange (the tile's last
+    // block reads every partial), b ~ 0.33 us per step (0.45 at 160 couts): S = sqrt(b * steps / 2.8), capped by the CUs,
+    // by two slices per block and by 4; below 128 steps the split never paid (profiles/r05_half_tile_ab.txt).
+    // desc.ksplit: 0 = this rule (automatic tile choice only), 1 = never, n = n blocks per tile (tests, A/B).  Needs the
+    // per-stream workspace and tickets: without them (first use inside a hipGraph capture) the launch does not split.
+    const int cus = 8 * (32 - (reserved_cus() + 7) / 8);
+    const int kchunks = p.d.cin / 32;
+    int S = 1;
+    if (p.d.ksplit > 1) S = std::min(p.d.ksplit, kchunks);
+    else if (p.d.ksplit == 0 && p.d.wide_tile != 5 && 9 * kchunks >= 128) {
+      const double want = std::sqrt((NT == 5 ? 0.45 : 0.33) * 9.0 * kchunks / 2.8);
+      // wide_tile 1 = the caller says the launch has the GPU to itself (forward); 0 = a weight gradient runs beside it
+      // (data gradients): there the split may fill half the CUs only -- in ResNet18 / 64x64 training steps 256 split
+      // blocks beside the weight gradient cost 60 us per step more than 128 unsplit ones (profiles/r05_half_tile_ab.txt)
+      const int room = p.d.wide_tile == 1 ? cus : cus / 2;
+      S = std::min(std::min(room / std::max(items, 1), kchunks / 2), std::min(4, (int)(want + 0.5)));
+    }
+    if (S >= 2 && items <= kMaxSplitTiles) {
+      float* ws = det_rows(st, (size_t)items * S * BN * 256);
+      unsigned* tickets = ws ? split_tickets(st) : nullptr;
+      if (ws && tickets) {
+        p.ksplit = S; p.k_ws = ws; p.k_tickets = tickets;
+        items *= S;
+      }
+    }
+  }
   p.per_xcd = (items + 7) / 8;
   size_t shmem = 2 * (size_t)hg.a_bytes + (size_t)3 * BN * BK * 2;
   const size_t epi = conv_epilogue_lds_bytes<NT, NWV>();
@@ -775,7 +903,7 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
 #undef NBDT_GO
 #undef NBDT_KERNEL
   g_last_igemm = KIND == 0 ? (PAD ? "conv3x3_pp_kernel/pad" : "conv3x3_pp_kernel")
-                           : KIND == 3 ? "conv3x3_pp_kernel/half" : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
+                           : KIND == 3 ? (p.ksplit > 1 ? "conv3x3_pp_kernel/half/ksplit" : "conv3x3_pp_kernel/half") : KIND == 1 ? "conv3x3_pp_kernel/4w" : "conv3x3_halo_kernel";
   return NBDT_OK;
 }
 

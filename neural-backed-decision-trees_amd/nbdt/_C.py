@@ -33,7 +33,7 @@ class ConvDesc(ctypes.Structure):
         ("out_bs", c_int32), ("out_hs", c_int32), ("out_ws", c_int32), ("out_base", c_int32),
         ("accumulate", c_int32),
         ("wide_tile", c_int32),
-        ("reserved", c_int32),
+        ("ksplit", c_int32),
         ("w_tiled", ctypes.c_uint64),
     ]
 

@@ -85,6 +85,11 @@ def _fill(desc_arr, values):
 # ------------------------------------------------------------------------------------------------
 # tap tables
 
+# nbdt_conv_desc.ksplit of the descriptors built below (0 automatic, 1 never split K): A/B measurements set it before
+# an engine plans its launches
+CONV_KSPLIT = {"fwd": 0, "dgrad": 0}
+
+
 def conv_fwd_desc(B, Hi, Wi, cin, cout, k, stride):
     """Conv2d(k in {1,3}, padding=k//2, stride) forward: in [B,Hi,Wi,cin] -> out [B,Hi/s,Wi/s,cout]."""
     assert k in (1, 3) and Hi % stride == 0 and Wi % stride == 0
@@ -107,6 +112,7 @@ def conv_fwd_desc(B, Hi, Wi, cin, cout, k, stride):
     d.out_bs, d.out_hs, d.out_ws, d.out_base = (Ho + 2) * rowo, rowo, cout, rowo + cout
     d.accumulate = 0
     d.wide_tile = 1      # forward launches run alone on the GPU (data gradients share it with weight gradients)
+    d.ksplit = CONV_KSPLIT["fwd"]
     return d
 
 
@@ -143,6 +149,7 @@ def conv_dgrad_descs(B, Hi, Wi, cin, cout, k, stride, accumulate=False):
         d.in_bs, d.in_hs, d.in_ws, d.in_base = (Ho + 2) * rowg, rowg, cout, 0
         d.out_bs, d.out_hs, d.out_ws, d.out_base = (Hi + 2) * rowx, rowx, cin, rowx + cin
         d.accumulate = 1 if accumulate else 0
+        d.ksplit = CONV_KSPLIT["dgrad"]
         return [d]
     # stride 2, 3x3: padded input row hp = 2*ho + r.  hp odd (=2i+1): r=1, ho=i.
     # hp even (=2i+2): r=0 -> ho=i+1 ; r=2 -> ho=i.  Same for columns.  g rows are padded (+1).

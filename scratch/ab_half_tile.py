@@ -12,6 +12,10 @@ from nbdt import ops
 DEV = "cuda:0"
 SHAPES = [(256, 8, 640), (256, 16, 320), (256, 32, 160), (128, 16, 256), (128, 8, 512), (128, 32, 128), (128, 16, 128), (128, 8, 256),
           (512, 8, 640)]
+MODES = [(3, 0), (5, 0), (2, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "ksplit":
+    MODES = [(5, 1), (5, 2), (5, 4), (5, 8), (0, 0)]
+    sys.argv.pop(1)
 if len(sys.argv) > 1:
     SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 
@@ -40,15 +44,15 @@ for (B, H, C) in SHAPES:
     out = ops.padded(B, H, H, C, DEV)
     fl = 2.0 * B * H * H * C * C * 9
     line = f"B={B} {H}x{H} C={C} ({fl * 1e-9:6.1f} GF):"
-    for mode in (3, 5, 2):
-        d = ops.conv_fwd_desc(B, H, H, C, C, 3, 1); d.wide_tile = mode; d.w_tiled = wt.data_ptr()
-        (dd,) = ops.conv_dgrad_descs(B, H, H, C, C, 3, 1); dd.wide_tile = mode; dd.w_tiled = wdt.data_ptr()
+    for mode, ks in MODES:
+        d = ops.conv_fwd_desc(B, H, H, C, C, 3, 1); d.wide_tile = mode; d.w_tiled = wt.data_ptr(); d.ksplit = ks
+        (dd,) = ops.conv_dgrad_descs(B, H, H, C, C, 3, 1); dd.wide_tile = mode; dd.w_tiled = wdt.data_ptr(); dd.ksplit = ks
         try:
             t1 = timed(lambda: ops.conv_igemm(d, x, wb, out, bn_scratch=part))
             k = ops.last_igemm_kernel()
             t2 = timed(lambda: ops.conv_igemm(d, x, wb, out, residual=r, bn_scratch=part))
             t3 = timed(lambda: ops.conv_igemm_bnbwd(dd, gy, wd, out, x, mean, rstd, gamma, beta, part))
-            line += f"\n   wide_tile={mode} {k:24s} fwd+stats {t1:6.1f} us ({fl / t1 * 1e-6:5.0f} TF/s)  +residual {t2:6.1f}  dgrad+bn {t3:6.1f}"
+            line += f"\n   wide_tile={mode} ksplit={ks} {k:30s} fwd+stats {t1:6.1f} us ({fl / t1 * 1e-6:5.0f} TF/s)  +residual {t2:6.1f}  dgrad+bn {t3:6.1f}"
         except Exception as e:
             line += f"\n   wide_tile={mode}: {str(e)[:80]}"
     print(line, flush=True)

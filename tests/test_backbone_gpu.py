@@ -695,6 +695,33 @@ def test_pingpong_kernel_forced_on_small_shapes(B, H, W, cin, cout):
     ops.bn_finalize(out_h, part_ref, m_b, r_b)
     np.testing.assert_allclose(m_a.cpu().numpy(), m_b.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r_a.cpu().numpy(), r_b.cpu().numpy(), rtol=1e-5)
+    # ... and split K (desc.ksplit blocks per half tile, each a range of the 32-channel slices; partial sums through the
+    # per-stream workspace, the tile's last block adds them in split order): another summation order, so equal to the
+    # unsplit kernel up to the bf16 rounding of the output -- and the same bits every time, whoever comes last
+    for ks in sorted({2, cin // 32} - {1}) if cin >= 64 else ():
+        dk = desc(5)
+        dk.ksplit = ks
+        outs_k, parts_k = [], []
+        for _ in range(3):
+            o = ops.padded(B, H, W, cout, DEV)
+            pk = torch.full_like(part_half, float("nan"))
+            ops.conv_igemm(dk, xp, wb, o, residual=rp, bn_scratch=pk)
+            assert ops.last_igemm_kernel() == "conv3x3_pp_kernel/half/ksplit"
+            outs_k.append(o)
+            parts_k.append(pk)
+        assert torch.equal(outs_k[0], outs_k[1]) and torch.equal(outs_k[0], outs_k[2])
+        if cout % 64 == 0:
+            assert torch.equal(parts_k[0], parts_k[1])
+        else:      # one 32-channel cout tile: the block's statistics are summed with LDS atomics (conv_common.h)
+            np.testing.assert_allclose(parts_k[0].cpu().numpy(), parts_k[1].cpu().numpy(), rtol=1e-4, atol=1e-4)
+        _close_bf16(ops.interior(outs_k[0]), ref + rf, f"half tiles, ksplit {ks}")
+        _check_border_zero(outs_k[0])
+        a, b = ops.interior(outs_k[0]).float(), ops.interior(out_h).float()
+        assert ((a - b).abs() <= 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 1e-4).all()
+        m_k, r_k = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+        ops.bn_finalize(outs_k[0], parts_k[0], m_k, r_k)
+        np.testing.assert_allclose(m_k.cpu().numpy(), m_b.cpu().numpy(), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(r_k.cpu().numpy(), r_b.cpu().numpy(), rtol=1e-3)
     # residual + fused BatchNorm statistics epilogue
     n_part = ((B * H * W + 255) // 256) * 2 * cout
     part_pp = torch.full((n_part,), float("nan"), device=DEV)
@@ -744,6 +771,18 @@ def test_pingpong_kernel_dgrad_with_bn_backward_epilogue(B, H, W, cin, cout):
     gx_ref = F.conv_transpose2d(gt, w_oihw, padding=1).permute(0, 2, 3, 1)
     _close_bf16(ops.interior(outs[0]), gx_ref, "pp dgrad")
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
+    # split K under the BatchNorm-backward epilogue: the tile's last block holds the full sums, the epilogue is unchanged
+    (dk,) = ops.conv_dgrad_descs(B, H, W, cin, cout, 3, 1)
+    _force(dk, 5).w_tiled = wdt.data_ptr()
+    dk.ksplit = 2
+    ga_k = ops.padded(B, H, W, cin, DEV)
+    part_k = torch.full((((B * H * W + 255) // 256) * 2 * cin,), float("nan"), device=DEV)
+    ops.conv_igemm_bnbwd(dk, gp, wd, ga_k, xp, mean, rstd, gamma, beta, part_k)
+    assert ops.last_igemm_kernel() == "conv3x3_pp_kernel/half/ksplit"
+    _close_bf16(ops.interior(ga_k), gx_ref, "pp dgrad, split K")
+    dsum_k, dg_k, db_k = torch.empty(2 * cin, device=DEV), torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
+    ops.bn_bwd_fused(ga_k, xp, mean, rstd, gamma, beta, part_k, dsum_k, dg_k, db_k, ops.padded(B, H, W, cin, DEV))
+    np.testing.assert_allclose(dsum_k.cpu().numpy(), sums[1].cpu().numpy(), rtol=2e-2, atol=2e-2 * sums[1].abs().max().item())
     scale = sums[1].abs().max().item()
     np.testing.assert_allclose(sums[0].cpu().numpy(), sums[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
     np.testing.assert_allclose(sums[2].cpu().numpy(), sums[1].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)

@@ -66,14 +66,14 @@ int nbdt_version(void);
  * nbdt_se_gate_bwd's parameter gradients) -- and the rules layer, which has no atomics. */
 int nbdt_set_deterministic(int32_t on);
 int nbdt_get_deterministic(void);
-/* Epilogue of the K-split weight-gradient kernel (nbdt_conv_wgrad on the 3x3 stride-1 shapes; process-wide, default 0).
- * 0: fp32 atomics into dw.
+/* Epilogue of the K-split weight-gradient kernel (nbdt_conv_wgrad on the 3x3 stride-1 shapes; process-wide, default 1).
  * 1: each (pixel split, tile) block writes its partial sums with plain stores into that split's copy of dw in the
  *    per-(device, stream) workspace (the one deterministic mode uses, same hipGraph rule: one eager launch first) and
  *    a streaming pass adds the copies to dw in split order: the sum no longer depends on block timing.  The L2 retires
- *    fp32 atomics at ~1.2 TB/s whatever their shape, so alone the launch is 4-8 % faster with the fold included; inside
- *    the training step the fold's HBM traffic competes with the BatchNorm backward passes and the step time does not
- *    move (profiles/r05_wgrad_store_epilogue_ab.txt).  Deterministic mode always takes this path for that kernel. */
+ *    fp32 atomics at ~1.2 TB/s whatever their shape: alone the launch is 4-8 % faster on the WRN-28-10 shapes and 20-27 %
+ *    on ResNet18's at batch 128 (fold included); training steps: WRN-28-10 unchanged, ResNet18 1-4 % faster
+ *    (profiles/r05_wgrad_store_epilogue_ab.txt).  Launches with more than 64 pixel splits keep the atomics.
+ * 0: fp32 atomics into dw (rounds 3-4).  Deterministic mode always takes the stores for that kernel. */
 int nbdt_set_wgrad_store_epilogue(int32_t on);
 int nbdt_get_wgrad_store_epilogue(void);
 /* CUs (0..128, process-wide, default 0) the one-block-per-CU MFMA kernels leave free: the persistent forward / data-

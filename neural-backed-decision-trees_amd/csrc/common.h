@@ -85,7 +85,7 @@ struct DeviceAttr {
 // epilogue), whose order changes from run to run.  With the switch on, each of them adds into a zeroed library-owned
 // row per block / per pixel split instead -- one add per address -- and det_fold() sums the rows in index order.
 bool deterministic();
-// K-split weight gradient: plain stores into per-split copies + det_fold instead of fp32 atomics into dw (default off; deterministic mode: always)
+// K-split weight gradient: plain stores into per-split copies + det_fold instead of fp32 atomics into dw (default on; deterministic mode: always)
 bool wgrad_store_epilogue();
 // CUs the one-block-per-CU MFMA kernels leave free (nbdt_set_reserved_cus): a collective's kernels (RCCL, one block per
 // channel) running beside the backward pass get them, instead of making persistent blocks wait for a CU they hold

@@ -100,7 +100,7 @@ extern "C" int nbdt_set_deterministic(int32_t on) {
 extern "C" int nbdt_get_deterministic(void) { return nbdt::deterministic() ? 1 : 0; }
 
 namespace nbdt {
-static std::atomic<int> g_wgrad_store{0};      // profiles/r05_wgrad_store_epilogue_ab.txt: faster alone, no gain inside the step
+static std::atomic<int> g_wgrad_store{1};      // profiles/r05_wgrad_store_epilogue_ab.txt
 bool wgrad_store_epilogue() { return g_wgrad_store.load(std::memory_order_relaxed) != 0; }
 }  // namespace nbdt
 extern "C" int nbdt_set_wgrad_store_epilogue(int32_t on) {

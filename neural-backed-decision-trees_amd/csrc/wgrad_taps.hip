@@ -1315,14 +1315,19 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   // K-split kernel: the L2 retires fp32 atomics at ~1.2 TB/s whatever their shape (profiles/r05_atomic_pattern_probe.txt),
   // so its ~47 MB of partial sums per launch are written with plain stores into one copy of dw per pixel split and a
   // streaming pass adds the copies to dw in split order (which also makes the result independent of block timing)
-  p.store = (KIND == 3 && (wgrad_store_epilogue() || deterministic())) ? 1 : 0;
+  // (not with more than 64 splits -- 2 tiles of a 64-channel layer -- where the fold reads more than the atomics cost)
+  p.store = (KIND == 3 && ((wgrad_store_epilogue() && p.splits <= 64) || deterministic())) ? 1 : 0;
   if (p.store || deterministic()) {
     float* rows = det_rows(st, (size_t)p.splits * dw_elems);
-    if (!rows) return nbdt::fail(NBDT_ENOMEM, "weight gradient: %s (%s)", "no workspace for the per-split gradients",
-                                 nbdt::det_rows_why());
-    if (!p.store) NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
-    p.dw = rows;
-    p.dw_split_stride = (long long)dw_elems;
+    if (!rows && !deterministic()) {
+      p.store = 0;      // no workspace (first use inside a hipGraph capture): the atomics need none
+    } else {
+      if (!rows) return nbdt::fail(NBDT_ENOMEM, "weight gradient: %s (%s)", "no workspace for the per-split gradients",
+                                   nbdt::det_rows_why());
+      if (!p.store) NBDT_HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)p.splits * dw_elems * sizeof(float), st));
+      p.dw = rows;
+      p.dw_split_stride = (long long)dw_elems;
+    }
   }
   void* args[] = {(void*)&p};
   NBDT_HIP_CHECK(hipLaunchKernel(fn, dim3(p.per_xcd * 8), dim3(KIND == 2 ? 768 : (KIND == 0 ? 256 : 512)), args, shmem, st));

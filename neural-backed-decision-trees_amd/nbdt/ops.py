@@ -33,7 +33,7 @@ def is_deterministic():
 
 
 def set_wgrad_store_epilogue(on):
-    """K-split weight gradient: 1 = plain stores into per-split copies + a fold pass, 0 (default) = fp32 atomics into dw
+    """K-split weight gradient: 1 (default) = plain stores into per-split copies + a fold pass, 0 = fp32 atomics into dw
     (nbdt_set_wgrad_store_epilogue in include/nbdt_hip.h)."""
     check(lib().nbdt_set_wgrad_store_epilogue(1 if on else 0))
 

@@ -966,23 +966,28 @@ def test_weight_gradient_kernel_variants(B, H, W, cin, cout):
         np.testing.assert_allclose(dw.cpu().numpy(), gw_ref.numpy(), **tol)
         ops.conv_wgrad(d, xp, gp, dw)
         np.testing.assert_allclose(dw.cpu().numpy(), 2 * gw_ref.numpy(), rtol=2e-3, atol=2 * tol["atol"])
-    # the K-split kernel's other epilogue: plain stores into one copy of dw per pixel split + a fold in split order
-    # (nbdt_set_wgrad_store_epilogue) -- the same sums, += semantics, and the same bits twice (no atomics left)
-    assert not ops.wgrad_store_epilogue()
-    ops.set_wgrad_store_epilogue(True)
+    # the K-split kernel's two epilogues: plain stores into one copy of dw per pixel split + a fold in split order (default;
+    # the same bits twice, no atomics left) and fp32 atomics into dw (nbdt_set_wgrad_store_epilogue(0)) -- the same sums,
+    # += semantics both
+    assert ops.wgrad_store_epilogue()
     try:
-        d = ops.conv_wgrad_desc(B, H, W, cin, cout, 3, 1)
-        d.variant = 5
-        runs = []
-        for _ in range(2):
-            dw = torch.full((cout, 9, cin), 0.5, dtype=torch.float32, device=DEV)
-            ops.conv_wgrad(d, xp, gp, dw)
-            assert ops.last_wgrad_kernel() == "conv_wgrad_ks_kernel"
-            runs.append(dw)
-        np.testing.assert_allclose(runs[0].cpu().numpy() - 0.5, gw_ref.numpy(), rtol=2e-3, atol=tol["atol"] + 1e-6)
-        assert torch.equal(runs[0], runs[1])
+        per_mode = {}
+        for mode in (True, False):
+            ops.set_wgrad_store_epilogue(mode)
+            d = ops.conv_wgrad_desc(B, H, W, cin, cout, 3, 1)
+            d.variant = 5
+            runs = []
+            for _ in range(2):
+                dw = torch.full((cout, 9, cin), 0.5, dtype=torch.float32, device=DEV)
+                ops.conv_wgrad(d, xp, gp, dw)
+                assert ops.last_wgrad_kernel() == "conv_wgrad_ks_kernel"
+                runs.append(dw)
+            np.testing.assert_allclose(runs[0].cpu().numpy() - 0.5, gw_ref.numpy(), rtol=2e-3, atol=tol["atol"] + 1e-6)
+            per_mode[mode] = runs
+        assert torch.equal(per_mode[True][0], per_mode[True][1])
+        np.testing.assert_allclose(per_mode[True][0].cpu().numpy(), per_mode[False][0].cpu().numpy(), rtol=1e-4, atol=1e-4 * tol["atol"] + 1e-6)
     finally:
-        ops.set_wgrad_store_epilogue(False)
+        ops.set_wgrad_store_epilogue(True)
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 160, 320), (6, 16, 16, 320, 640), (64, 32, 32, 160, 320),

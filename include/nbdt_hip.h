@@ -247,9 +247,11 @@ typedef struct nbdt_wgrad_desc {
   int32_t w_ntaps;
   int32_t x_bs, x_hs, x_ws, x_base;
   int32_t g_bs, g_hs, g_ws, g_base;
-  int32_t variant;              /* dense 3x3 stride-1 launches: 0 = pick from the problem size; 2 = force the 8-wave
-                                   kernel (two wave groups), 3 = force the 4-wave one, 4 = force the 12-wave kernel
-                                   (three wave groups, one kernel row each) -- tests, A/B measurements */
+  int32_t variant;              /* dense 3x3 stride-1 launches: 0 = pick from the problem size (the K-split 8-wave kernel
+                                   from 64 pixel stages on, else the 4-wave one); 2 = force the tap-split 8-wave kernel
+                                   (two wave groups, taps divided between them), 3 = force the 4-wave one, 4 = force the
+                                   12-wave kernel (three wave groups, one kernel row each), 5 = force the K-split 8-wave
+                                   kernel (every wave all nine taps, the groups halve the pixels) -- tests, A/B */
   int32_t cu_budget;            /* dense 3x3 stride-1 launches: 0 = size the pixel split for all 256 CUs; n = for n of
                                    them (32..256), so that an HBM-bound pass launched on another stream keeps the
                                    rest: a weight-gradient block takes a CU's whole register file, the two kernels

@@ -20,6 +20,8 @@ import torch
 
 from nbdt import ops
 
+SIDE_STREAM_PRIORITY = 0       # HIP stream priority of the weight-gradient stream (A/B: scratch/ab_stream_priority.py)
+
 ALIGN = 8  # elements: keeps every parameter 16-byte aligned in the bf16 mirror
 
 
@@ -744,7 +746,7 @@ class WRNEngine(_Engine):
         # (76 KB, 4 waves) fit on one CU together, and the two kernels stall on different things, so running
         # conv.wgrad next to the dgrad / BatchNorm-backward chain instead of in front of it is worth 3.9 % of the
         # step (21.62 -> 20.80 ms, same-box A/B; engine.set_overlap(False) restores the single-stream order).
-        self._side = torch.cuda.Stream(device=self.device)     # engine.set_overlap(False) puts everything back
+        self._side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY)     # engine.set_overlap(False) puts everything back
         for c in self.convs:                                   # on the caller's stream (profiling passes)
             c.side_stream = self._side
         # BatchNorm-backward passes beside the weight gradients on disjoint CUs: on by default, kept only if the
@@ -999,7 +1001,7 @@ class ResNetEngine(_Engine):
         self.store.add("linear.weight", (num_classes, cin), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.store.add("linear.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.finalize()
-        self._side = torch.cuda.Stream(device=self.device)     # weight gradients on a second stream (see WRNEngine)
+        self._side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY)     # weight gradients on a second stream (see WRNEngine)
         for c in self.convs:
             c.side_stream = self._side
         dev = self.device

@@ -72,7 +72,8 @@ int nbdt_get_deterministic(void);
  *    a streaming pass adds the copies to dw in split order: the sum no longer depends on block timing.  The L2 retires
  *    fp32 atomics at ~1.2 TB/s whatever their shape: alone the launch is 4-8 % faster on the WRN-28-10 shapes and 20-27 %
  *    on ResNet18's at batch 128 (fold included); training steps: WRN-28-10 unchanged, ResNet18 1-4 % faster
- *    (profiles/r05_wgrad_store_epilogue_ab.txt).  Launches with more than 64 pixel splits keep the atomics.
+ *    (profiles/r05_wgrad_store_epilogue_ab.txt).  Launches with more than 64 pixel splits keep the atomics, and so do
+ *    CU-budgeted launches (desc.cu_budget > 0: an HBM-bound pass runs beside them, the fold would compete with it).
  * 0: fp32 atomics into dw (rounds 3-4).  Deterministic mode always takes the stores for that kernel. */
 int nbdt_set_wgrad_store_epilogue(int32_t on);
 int nbdt_get_wgrad_store_epilogue(void);

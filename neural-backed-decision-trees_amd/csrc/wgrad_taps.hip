@@ -1315,8 +1315,11 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   // K-split kernel: the L2 retires fp32 atomics at ~1.2 TB/s whatever their shape (profiles/r05_atomic_pattern_probe.txt),
   // so its ~47 MB of partial sums per launch are written with plain stores into one copy of dw per pixel split and a
   // streaming pass adds the copies to dw in split order (which also makes the result independent of block timing)
-  // (not with more than 64 splits -- 2 tiles of a 64-channel layer -- where the fold reads more than the atomics cost)
-  p.store = (KIND == 3 && ((wgrad_store_epilogue() && p.splits <= 64) || deterministic())) ? 1 : 0;
+  // Not with more than 64 splits -- 2 tiles of a 64-channel layer -- where the fold reads more than the atomics cost, and
+  // not for a CU-budgeted launch: the caller runs an HBM-bound pass beside it (the BatchNorm backward of the CU-sharing
+  // schedule), the fold's ~110 MB would compete with exactly that, and the step does not get shorter
+  // (profiles/r05_wgrad_store_epilogue_ab.txt: WRN-28-10 at 512 images, where every such launch is budgeted).
+  p.store = (KIND == 3 && ((wgrad_store_epilogue() && p.splits <= 64 && p.d.cu_budget == 0) || deterministic())) ? 1 : 0;
   if (p.store || deterministic()) {
     float* rows = det_rows(st, (size_t)p.splits * dw_elems);
     if (!rows && !deterministic()) {

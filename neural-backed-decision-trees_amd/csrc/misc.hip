@@ -79,7 +79,32 @@ __global__ __launch_bounds__(256) void det_fold4_kernel(const float4* __restrict
   dst[i] = s;
 }
 
+// many rows of few elements (the stem weight gradient: ~1000 blocks x 27 * cout sums): 16 row lanes x 16 columns per block,
+// every lane sums its rows r = lane, lane + 16, ... in order, then the 16 lanes of a column are added in lane order
+__global__ __launch_bounds__(256) void det_fold_tall_kernel(const float* __restrict__ rows, int nrows, size_t n,
+                                                            float* __restrict__ dst) {
+  __shared__ float part[16][17];
+  const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + col;
+  float s = 0.f;
+  if (i < n)
+    for (int r = rl; r < nrows; r += 16) s += rows[(size_t)r * n + i];
+  part[rl][col] = s;
+  __syncthreads();
+  if (rl == 0 && i < n) {
+    float t = dst[i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][col];
+    dst[i] = t;
+  }
+}
+
 int det_fold(hipStream_t st, const float* rows, int nrows, size_t n, float* dst) {
+  if (nrows >= 64 && n <= 65536) {
+    hipLaunchKernelGGL(det_fold_tall_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, rows, nrows, n, dst);
+    NBDT_LAUNCH_CHECK();
+    return NBDT_OK;
+  }
   if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
     const size_t n4 = n / 4;
     hipLaunchKernelGGL(det_fold4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float4*)rows, nrows,
@@ -168,79 +193,116 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
 }
 
-// dw[co][27] += sum_pixels gy[pix][co] * img[tap]: per 64-pixel tile the gy tile [64][cout] and the patch tile
-// [64][28] go to LDS (a thread owns one pixel of the tile for both loads: one (b, y, x) decomposition per tile, 16-byte
-// bf16 loads of gy), then thread (k, co quad) accumulates 4 outputs with one ds_read_b32 + one ds_read_b128 per pixel.
-// (Round 1's form decomposed the pixel index for every ELEMENT it loaded and read two LDS words per multiply-add:
-// 100 us for the WRN stem at 512 images, 210 us for ResNet18's at 128 x 64x64.)
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gy,
-                                                         int B, int H, int W, int cout, int cpad, int stride,
-                                                         int tiles_per_block, float* __restrict__ dw,
-                                                         int row_stride) {
-  // row_stride: 0 = every block adds into dw; deterministic mode: cout*27, a zeroed row per block (det_fold sums them)
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // gy tile [64][cout] then patch tile [64][28]
+// dw[co][27] += sum_pixels gy[pix][co] * img[tap], on the matrix pipes (round 5).  Rounds 2-4 had thread (k, co quad)
+// accumulate 4 outputs with one ds_read_b32 + one ds_read_b128 per pixel: two LDS words per four multiply-adds, and a CU
+// completes one LDS read instruction per ~8 cycles -- 117 us for ResNet18's stem at 128 x 64x64, of which the 67 MB of gy are
+// 17.  Here dw^T = sum over pixels of gy[pix][co] (x) patch[pix][k] goes through v_mfma_f32_32x32x2_f32 -- fp32 operands,
+// the arithmetic of the scalar form -- with K = pixels: per 64-pixel tile the gy tile [64][cout] and the patch tile [64][27 -> 32]
+// go to LDS (a thread owns one pixel of the tile for both loads: one (b, y, x) decomposition per tile), wave w of the block
+// owns 16 of the tile's pixels, per pixel PAIR one ds_read_b32 of the patch row and one per 32 couts of the gy row feed
+// one MFMA each: 24 reads per wave and tile instead of 256.  The four waves' 32 x 32 x CO_T sums meet in LDS at the end and
+// every block writes ONE row of sums; det_fold adds the ~1000 rows to dw in block order (atomics from 1024 blocks onto
+// the same 27 * cout addresses were a fixed 43 us of the launch).  WRN stem at 512 images 90 -> 52 us, ResNet18's at
+// 128 x 64x64 117 -> 72, EfficientNet-B0's (stride 2, 128 x 224x224) 177 -> 115.
+typedef __attribute__((ext_vector_type(16))) float stem_f32x16;
+template <int CO_T>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ img, const bf16_t* __restrict__ gy,
+                                                              int B, int H, int W, int cout, int cpad, int stride,
+                                                              int tiles_per_block, float* __restrict__ dw, int row_stride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // gy tile [64][gp], patch tile [64][33]; then [4][CO_T][1024]
+  // row pitches: a thread owns a PIXEL when it fills the tiles, so lane l writes row l -- pitch 32 would put all 64 lanes of
+  // a patch store on two banks (that version ran at the scalar kernel's speed), cout + 32 the float4 stores of gy likewise.
+  // cout + 4 and 33: conflict-free stores, and the two pixels of a pair at most 2-way on the 24 reads per wave and tile.
+  const int gp = cout + 4;
+  constexpr int PP = 33;
   float* gl = lds;
-  float* pl = lds + 64 * cout;
+  float* pl = lds + 64 * gp;
   const int Ho = H / stride, Wo = W / stride;
   const int npix = B * Ho * Wo;
-  const int nq = cout / 4;                     // co quads
-  const int nwork = nq * 27;                   // (quad, k) pairs, each 4 outputs
-  constexpr int MAXW = 2;                      // pairs per thread: nwork <= 512, i.e. cout <= 72 (host checks cout*27 <= 2048)
-  float acc[MAXW][4];
-#pragma unroll
-  for (int j = 0; j < MAXW; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
-  // loader roles: thread -> (pixel of the tile, part): parts 0..c8-1 load 8 gy channels each, the others patch values
   const int c8 = cout / 8;
-  const int lp = threadIdx.x & 63, part = threadIdx.x >> 6;      // 4 parts per pixel
+  const int lp = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l32 = lane & 31, half = lane >> 5;
+  stem_f32x16 acc[CO_T];
+#pragma unroll
+  for (int c = 0; c < CO_T; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   for (int t = 0; t < tiles_per_block; ++t) {
     const int p0 = (blockIdx.x * tiles_per_block + t) * 64;
     if (p0 >= npix) break;
     __syncthreads();
     {
-      const int pp = p0 + lp;
-      const bool live = pp < npix;
+      // every load unconditional on a clamped address, the mask applied to the VALUE: a `live ? load : 0` makes hipcc wait
+      // for each load before it issues the next (round 1's lesson) -- 8 + 2 serial HBM round trips per tile
+      const int pp_raw = p0 + lp;
+      const bool live = pp_raw < npix;
+      const int pp = live ? pp_raw : npix - 1;
       const int x = pp % Wo, y = (pp / Wo) % Ho, b = pp / (Wo * Ho);
-      // gy: chunks part, part+4, ... of this pixel
-      for (int ck = part; ck < c8; ck += 4) {
-        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (live) unpack8(*(const u32x4_t*)(gy + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + ck * 8), f);
-        *(float4*)(gl + lp * cout + ck * 8) = make_float4(f[0], f[1], f[2], f[3]);
-        *(float4*)(gl + lp * cout + ck * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+      constexpr int GMAX = 3;                    // cout <= 72: at most 9 chunks of 8 channels, 4 parts
+      u32x4_t gv[GMAX];
+#pragma unroll
+      for (int i = 0; i < GMAX; ++i) {
+        const int ck = part + 4 * i;
+        const int ckc = ck < c8 ? ck : c8 - 1;
+        gv[i] = *(const u32x4_t*)(gy + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * cpad + ckc * 8);
       }
-      // patch: taps part, part+4, ... (27 values per pixel, row pitch 28)
-      for (int k = part; k < 27; k += 4) {
-        const int r = k / 9, s = (k / 3) % 3, ci = k % 3;
-        const int yy = y * stride + r - 1, xx = x * stride + s - 1;
-        float v = 0.f;
-        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + ci) * H + yy) * W + xx];
-        pl[lp * 28 + k] = v;
+      float pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = part + 4 * i;              // 0..31; columns 27..31 are zero
+        const int kc = k < 27 ? k : 26;
+        const int r = kc / 9, s2 = (kc / 3) % 3, ci = kc % 3;
+        const int yy = y * stride + r - 1, xx = x * stride + s2 - 1;
+        const bool in = k < 27 && live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        const float v = img[(((size_t)b * 3 + ci) * H + yc) * W + xc];
+        pv[i] = in ? v : 0.f;
       }
+#pragma unroll
+      for (int i = 0; i < GMAX; ++i) {
+        const int ck = part + 4 * i;
+        if (ck < c8) {
+          float f[8];
+          unpack8(gv[i], f);
+          const float m = live ? 1.f : 0.f;
+          *(float4*)(gl + lp * gp + ck * 8) = make_float4(f[0] * m, f[1] * m, f[2] * m, f[3] * m);
+          *(float4*)(gl + lp * gp + ck * 8 + 4) = make_float4(f[4] * m, f[5] * m, f[6] * m, f[7] * m);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pl[lp * PP + part + 4 * i] = pv[i];
     }
     __syncthreads();
+    // A[i = co][k = pixel of the pair], B[k][j = tap]: lane l holds A[l & 31][l >> 5] and B[l >> 5][l & 31]
 #pragma unroll
-    for (int j = 0; j < MAXW; ++j) {
-      const int o = threadIdx.x + 256 * j;
-      if (o < nwork) {
-        const int q = o / 27, k = o - q * 27;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-        for (int pp = 0; pp < 64; ++pp) {
-          const float pv = pl[pp * 28 + k];
-          const float4 g = *(const float4*)(gl + pp * cout + q * 4);
-          a0 += g.x * pv; a1 += g.y * pv; a2 += g.z * pv; a3 += g.w * pv;
-        }
-        acc[j][0] += a0; acc[j][1] += a1; acc[j][2] += a2; acc[j][3] += a3;
+    for (int pr = 0; pr < 8; ++pr) {
+      const int pix = wave * 16 + pr * 2 + half;
+      const float bv = pl[pix * PP + l32];
+#pragma unroll
+      for (int c = 0; c < CO_T; ++c) {
+        const int co = c * 32 + l32;
+        const float av = co < cout ? gl[pix * gp + co] : 0.f;
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
       }
     }
   }
+  // ---- the four waves' sums -> LDS -> one add per (co, k) and block.  acc[c][r]: co = c*32 + 8*(r/4) + 4*half + r%4, k = l32
+  __syncthreads();
+  float* red = lds + wave * (CO_T * 1024);
 #pragma unroll
-  for (int j = 0; j < MAXW; ++j) {
-    const int o = threadIdx.x + 256 * j;
-    if (o < nwork) {
-      const int q = o / 27, k = o - q * 27;
+  for (int c = 0; c < CO_T; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        atomicAdd(dw + (size_t)blockIdx.x * row_stride + (q * 4 + i) * 27 + k, acc[j][i]);
+    for (int r = 0; r < 16; ++r) red[c * 1024 + (8 * (r / 4) + 4 * half + (r % 4)) * 32 + l32] = acc[c][r];
+  __syncthreads();
+  for (int o = threadIdx.x; o < CO_T * 1024; o += 256) {
+    const int co = o >> 5, k = o & 31;
+    if (co < cout && k < 27) {
+      const float s4 = (lds[o] + lds[CO_T * 1024 + o]) + (lds[2 * CO_T * 1024 + o] + lds[3 * CO_T * 1024 + o]);
+      // row_stride != 0: this block's own row of the workspace, every entry written exactly once (det_fold adds the rows
+      // to dw in block order); 0: no workspace, atomics into dw -- ~1000 blocks on the same 27 * cout addresses
+      if (row_stride) dw[(size_t)blockIdx.x * row_stride + co * 27 + k] = s4;
+      else atomicAdd(dw + co * 27 + k, s4);
     }
   }
 }
@@ -269,17 +331,23 @@ extern "C" int nbdt_stem_wgrad(const float* img, const void* gy, int32_t B, int3
   int blocks = tiles < 1024 ? tiles : 1024;
   const int tpb = (tiles + blocks - 1) / blocks;
   blocks = (tiles + tpb - 1) / tpb;
-  const size_t shmem = (size_t)(64 * cout_real + 64 * 28) * sizeof(float);
+  const int co_t = (cout_real + 31) / 32;
+  size_t shmem = (size_t)(64 * (cout_real + 4) + 64 * 33) * sizeof(float);
+  if (shmem < (size_t)4 * co_t * 1024 * sizeof(float)) shmem = (size_t)4 * co_t * 1024 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const int nout = cout_real * 27;
-  float* target = dw;
-  if (deterministic()) {
-    target = det_rows(st, (size_t)blocks * nout);
-    if (!target) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
-    NBDT_HIP_CHECK(hipMemsetAsync(target, 0, (size_t)blocks * nout * sizeof(float), st));
+  // one row of sums per block + a fold in block order (run-to-run identical bits); atomics only without a workspace
+  // (first use inside a hipGraph capture) -- and never in deterministic mode
+  float* target = det_rows(st, (size_t)blocks * nout);
+  if (!target) {
+    if (deterministic()) return nbdt::fail(NBDT_ENOMEM, "deterministic mode: %s (%s)", "no workspace for the per-block rows", nbdt::det_rows_why());
+    target = dw;
   }
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), shmem, st, img,
-                     (const bf16_t*)gy, B, H, W, cout_real, cpad, stride, tpb, target, target == dw ? 0 : nout);
+#define NBDT_STEM(T)                                                                                                  \
+  hipLaunchKernelGGL(stem_wgrad_mfma_kernel<T>, dim3(blocks), dim3(256), shmem, st, img, (const bf16_t*)gy, B, H, W,  \
+                     cout_real, cpad, stride, tpb, target, target == dw ? 0 : nout)
+  if (co_t == 1) NBDT_STEM(1); else if (co_t == 2) NBDT_STEM(2); else NBDT_STEM(3);
+#undef NBDT_STEM
   NBDT_LAUNCH_CHECK();
   if (target != dw) return det_fold(st, target, blocks, (size_t)nout, dw);
   return NBDT_OK;

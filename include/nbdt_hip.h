@@ -204,6 +204,13 @@ typedef struct nbdt_conv_desc {
   uint64_t w_tiled;             /* 0, or device pointer to the same weights pre-arranged by nbdt_weight_tile_batched
                                    (only dense 3x3 stride-1 launches with the identity tap map use it) */
 } nbdt_conv_desc;
+/* Host only, no device work: which kernel form the launches below pick for this descriptor and this process's reserved
+ * CUs (nbdt_set_reserved_cus) -- so that the launch rules can be tested and planned with without a GPU.
+ * form: 0 = first-generation implicit GEMM (strided / 1x1 / anything that is not a dense 3x3 stride-1 conv over a padded
+ * tensor), 1 = 4-wave 256-pixel kernels (no DMA-ordered weights), 2 = ping-pong kernel on 512-pixel tiles, 3 = the same with
+ * the padded LDS pitch, 4 = ping-pong kernel on 256-pixel half tiles; ksplit: blocks per half tile the rule asks for
+ * (form 4; a launch without its per-stream workspace -- first use inside a hipGraph capture -- runs unsplit). */
+int nbdt_conv_plan(const nbdt_conv_desc* d, int32_t* form, int32_t* ksplit);
 /* in/out/w bf16; residual (nullable) bf16 addressed like out and added before rounding */
 int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                     const void* residual, void* stream);

@@ -204,6 +204,7 @@ struct HaloGeom {
   int row_magic;       // ceil(65536 / lpitch): slot / lpitch == (slot * row_magic) >> 16 for slot < 2048
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
+int conv_ksplit_rule(const nbdt_conv_desc& d, int nt, int items);      // blocks per half tile the launch rule asks for
 extern thread_local const char* g_last_wgrad;   // ... and the last nbdt_conv_wgrad call
 extern thread_local const char* g_last_igemm;   // name of the kernel the last nbdt_conv_igemm* call launched (tests)
 struct BnBwdArgs;

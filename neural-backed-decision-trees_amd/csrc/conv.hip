@@ -82,6 +82,33 @@ extern "C" int nbdt_conv_igemm_multi(const nbdt_conv_desc* descs, int32_t n, con
   return nbdt::conv_igemm_dma_multi(descs, n, in, w, out, (hipStream_t)stream);
 }
 
+extern "C" int nbdt_conv_plan(const nbdt_conv_desc* d, int32_t* form, int32_t* ksplit) {
+  NBDT_REQUIRE(d && form && ksplit, "null argument");
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const int64_t M64 = (int64_t)d->B * d->gh * d->gw;
+  NBDT_REQUIRE(M64 < (1ll << 31), "pixel grid too large");
+  *form = 0;
+  *ksplit = 1;
+  nbdt::HaloGeom hg;
+  if (!nbdt::conv_halo_applicable(d, (int)M64, &hg)) {
+    NBDT_REQUIRE(d->wide_tile != 2 && d->wide_tile != 4 && d->wide_tile != 5,
+                 "wide_tile = 2 / 4 / 5 (force 512-pixel tiles [with the padded LDS pitch] / half tiles): not a dense 3x3 stride-1 conv it fits");
+    return NBDT_OK;
+  }
+  if (hg.nwv != 8) { *form = 1; return NBDT_OK; }
+  if (hg.mw == 1) {
+    const int nt32 = d->cout / 32;
+    const int nt = nt32 % 5 == 0 ? 5 : (nt32 % 4 == 0 ? 4 : (nt32 % 2 == 0 ? 2 : 1));
+    const int items = (int)((M64 + 255) / 256) * (d->cout / (32 * nt));
+    *form = 4;
+    *ksplit = nbdt::conv_ksplit_rule(*d, nt, items);
+    return NBDT_OK;
+  }
+  *form = hg.pad ? 3 : 2;
+  return NBDT_OK;
+}
+
 extern "C" int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void* out,
                                const void* residual, void* stream) {
   return conv_igemm_impl(d, in, w, out, residual, nullptr, stream);

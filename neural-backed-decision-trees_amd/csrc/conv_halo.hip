@@ -812,6 +812,25 @@ static unsigned* split_tickets(hipStream_t st) {
   return t;
 }
 
+// Blocks per half tile the launch rule asks for (1 = no split); `items` = half tiles of the launch.  Pure host arithmetic
+// (nbdt_conv_plan reports it; launch_halo applies it when the workspace and tickets exist).
+int conv_ksplit_rule(const nbdt_conv_desc& d, int nt, int items) {
+  const int cus = 8 * (32 - (reserved_cus() + 7) / 8);
+  const int kchunks = d.cin / 32;
+  int S = 1;
+  if (d.ksplit > 1) S = std::min(d.ksplit, kchunks);
+  else if (d.ksplit == 0 && d.wide_tile != 5 && 9 * kchunks >= 128) {
+    const double want = std::sqrt((nt == 5 ? 0.45 : 0.33) * 9.0 * kchunks / 2.8);
+    // wide_tile 1 = the caller says the launch has the GPU to itself (forward); 0 = a weight gradient runs beside it
+    // (data gradients): there the split may fill half the CUs only -- in ResNet18 / 64x64 training steps 256 split
+    // blocks beside the weight gradient cost 60 us per step more than 128 unsplit ones (profiles/r05_half_tile_ab.txt)
+    const int room = d.wide_tile == 1 ? cus : cus / 2;
+    S = std::min(std::min(room / std::max(items, 1), kchunks / 2), std::min(4, (int)(want + 0.5)));
+  }
+  if (items > kMaxSplitTiles) S = 1;
+  return S < 1 ? 1 : S;
+}
+
 thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): which kernel the last launch used
 
 // KIND 0: conv3x3_pp_kernel<.., 8> (ping-pong), 1: conv3x3_pp_kernel<.., 4> (same segments, one group, two blocks
@@ -834,19 +853,8 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
     // by two slices per block and by 4; below 128 steps the split never paid (profiles/r05_half_tile_ab.txt).
     // desc.ksplit: 0 = this rule (automatic tile choice only), 1 = never, n = n blocks per tile (tests, A/B).  Needs the
     // per-stream workspace and tickets: without them (first use inside a hipGraph capture) the launch does not split.
-    const int cus = 8 * (32 - (reserved_cus() + 7) / 8);
-    const int kchunks = p.d.cin / 32;
-    int S = 1;
-    if (p.d.ksplit > 1) S = std::min(p.d.ksplit, kchunks);
-    else if (p.d.ksplit == 0 && p.d.wide_tile != 5 && 9 * kchunks >= 128) {
-      const double want = std::sqrt((NT == 5 ? 0.45 : 0.33) * 9.0 * kchunks / 2.8);
-      // wide_tile 1 = the caller says the launch has the GPU to itself (forward); 0 = a weight gradient runs beside it
-      // (data gradients): there the split may fill half the CUs only -- in ResNet18 / 64x64 training steps 256 split
-      // blocks beside the weight gradient cost 60 us per step more than 128 unsplit ones (profiles/r05_half_tile_ab.txt)
-      const int room = p.d.wide_tile == 1 ? cus : cus / 2;
-      S = std::min(std::min(room / std::max(items, 1), kchunks / 2), std::min(4, (int)(want + 0.5)));
-    }
-    if (S >= 2 && items <= kMaxSplitTiles) {
+    const int S = conv_ksplit_rule(p.d, NT, items);
+    if (S >= 2) {
       float* ws = det_rows(st, (size_t)items * S * BN * 256);
       unsigned* tickets = ws ? split_tickets(st) : nullptr;
       if (ws && tickets) {

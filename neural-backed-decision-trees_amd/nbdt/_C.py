@@ -73,6 +73,7 @@ SIGNATURES = {
     "nbdt_debug_last_igemm": (c_char_p, []),
     "nbdt_debug_last_wgrad": (c_char_p, []),
     "nbdt_conv_wgrad_blocks": (c_int, [_P]),
+    "nbdt_conv_plan": (c_int, [_P, _P, _P]),
     "nbdt_soft_forward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P]),
     "nbdt_soft_backward": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, _P, _P]),
     "nbdt_soft_tree_loss": (c_int, [c_void_p, _P, c_int, c_int64, c_int64, _P, c_float, c_float, c_float,

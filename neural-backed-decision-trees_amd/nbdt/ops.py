@@ -171,6 +171,17 @@ def conv_dgrad_descs(B, Hi, Wi, cin, cout, k, stride, accumulate=False):
     return out
 
 
+CONV_FORMS = {0: "conv_igemm_dma", 1: "4-wave 256-pixel", 2: "ping-pong 512-pixel", 3: "ping-pong 512-pixel, padded pitch",
+              4: "ping-pong 256-pixel half tiles"}
+
+
+def conv_plan(desc):
+    """(form, ksplit) a launch of this descriptor would take -- host only (nbdt_conv_plan in include/nbdt_hip.h)."""
+    form, ks = ctypes.c_int32(0), ctypes.c_int32(0)
+    check(lib().nbdt_conv_plan(ctypes.byref(desc), ctypes.byref(form), ctypes.byref(ks)))
+    return form.value, ks.value
+
+
 def conv_wgrad_desc(B, Hi, Wi, cin, cout, k, stride):
     Ho, Wo = Hi // stride, Wi // stride
     d = WgradDesc()

@@ -137,3 +137,19 @@ def test_timing_experiment_switches_do_not_compile_into_a_product_build(tmp_path
     # the shipped library is not a timing build
     import ctypes
     assert not hasattr(ctypes.CDLL(_C.libpath()), "nbdt_timing_build")
+
+
+def test_process_wide_switches_are_host_only():
+    """Setters / getters that take no device: callable on a box without a GPU, defaults as the header states."""
+    from nbdt import ops
+    assert ops.wgrad_store_epilogue() is True            # include/nbdt_hip.h: default 1
+    ops.set_wgrad_store_epilogue(False)
+    try:
+        assert ops.wgrad_store_epilogue() is False
+    finally:
+        ops.set_wgrad_store_epilogue(True)
+    assert ops.is_deterministic() is False and ops.reserved_cus() == 0
+    # the descriptor builders carry the A/B default of nbdt_conv_desc.ksplit (0 = the launch rule decides)
+    assert ops.conv_fwd_desc(8, 8, 8, 64, 64, 3, 1).ksplit == 0
+    (d,) = ops.conv_dgrad_descs(8, 8, 8, 64, 64, 3, 1)
+    assert d.ksplit == 0 and d.wide_tile == 0 and ops.conv_fwd_desc(8, 8, 8, 64, 64, 3, 1).wide_tile == 1

@@ -221,6 +221,72 @@ int nbdt_conv_igemm(const nbdt_conv_desc* d, const void* in, const void* w, void
  * Replaces the conv-transpose autograd of a strided nn.Conv2d (pytorchcv PreResUnit's first conv of a stage). */
 int nbdt_conv_igemm_multi(const nbdt_conv_desc* descs, int32_t n, const void* in, const void* w, void* out,
                           void* stream);
+
+/* ------------------------------------------------------------------ backbone: "slice list" convolutions (round 6)
+ * The shape-changing units of a (Wide)ResNet -- a stride-2 3x3 conv, its 1x1 stride-2 shortcut and their data
+ * gradients (nbdt/models/resnet.py:56-67; pytorchcv PreResUnit with stride 2 / a channel change behind
+ * nbdt/models/wideresnet.py:1-5) -- are not dense 3x3 stride-1 convolutions, but every one of them IS a sum of
+ * stride-1 tap-subset convolutions over tensors that share one padded pixel grid:
+ *   - the stride-2 forward conv over the space-to-depth copy of its input (nbdt_bn_apply_s2d): phase (p,q) of the
+ *     input holds 4 / 2 / 2 / 1 of the nine taps;
+ *   - the four output-parity classes of its data gradient over the output gradient (4 / 2 / 2 / 1 taps, strided
+ *     stores), the shortcut's data gradient being one more 1-tap term of class (even, even);
+ *   - conv2 + shortcut of the same unit: nine taps over conv2's input plus one tap over the unit's (space-to-depth)
+ *     input -- the residual add disappears into the K loop.
+ * A launch is therefore described as up to four CLASSES (disjoint output pixel maps over the same pixel grid), each an
+ * ordered list of 32-channel K SLICES: (input tensor, first channel, tap subset, where its weights are).  One kernel
+ * (csrc/conv_seg.hip: 8-wave ping-pong, LDS-resident halo slices, persistent blocks) runs them all.  The plan object
+ * owns the device-side step tables (which LDS-DMA piece goes out in which K step); weights are re-tiled into DMA
+ * order by nbdt_conv_seg_tile_weights whenever they change. */
+typedef struct nbdt_conv_seg_slice {
+  int32_t tensor;               /* input tensor index 0..3 */
+  int32_t ch0;                  /* first of the slice's 32 channels inside a pixel of that tensor (multiple of 8) */
+  int32_t ntaps;                /* 1..9 */
+  int32_t tap[9];               /* 3*R + S: input pixel (y + R - 1, x + S - 1) of the launch's pixel grid */
+  int32_t w_matrix;             /* weight matrix index 0..3 */
+  int32_t w_off[9];             /* per tap: element offset, inside a row of that matrix, of the slice's 32 k-values */
+} nbdt_conv_seg_slice;
+typedef struct nbdt_conv_seg_class {
+  int32_t nslices;              /* 1..NBDT_SEG_MAX_SLICES */
+  const nbdt_conv_seg_slice* slices;
+  int32_t out_bs, out_hs, out_ws, out_base;   /* element strides of the class's output pixel map (like nbdt_conv_desc) */
+} nbdt_conv_seg_class;
+#define NBDT_SEG_MAX_SLICES 64
+typedef struct nbdt_conv_seg_desc {
+  int32_t B, gh, gw;            /* pixel grid shared by every input tensor ([B][gh+2][gw+2][pix_stride], zero border)
+                                   and by the classes' output maps */
+  int32_t cout;                 /* multiple of 32; rows of every weight matrix */
+  int32_t ntensors;             /* 1..4 */
+  int32_t pix_stride[4];        /* elements per pixel of each input tensor */
+  int32_t nmatrices;            /* 1..4 */
+  int32_t w_row_stride[4];      /* elements per row of each weight matrix ([cout][row_stride] bf16) */
+  int32_t nclasses;             /* 1..4 */
+  nbdt_conv_seg_class cls[4];
+  int32_t tile;                 /* 0 = pick (512-pixel tiles when they give >= 3/4 of the CUs a block, else 256), 512, 256 */
+  int32_t nbuf;                 /* 0 = pick (2 halo buffers when every slice but a class's last has >= 2 taps, else 3), 2, 3 */
+} nbdt_conv_seg_desc;
+/* Host side only (no GPU needed until the first launch allocates the device tables): validates the description, picks
+ * tile / buffers, schedules the LDS-DMA pieces of every slice over the K steps before it; NBDT_EINVAL when the shape
+ * does not fit (tiles must be whole image rows / whole images, the halo buffers + weight ring must fit in 160 KB). */
+int nbdt_conv_seg_create(const nbdt_conv_seg_desc* d, void** plan);
+int nbdt_conv_seg_destroy(void* plan);
+/* what the plan chose: tile pixels, halo buffers, K steps per class (steps[4]), max LDS-DMA rounds in one step, bf16
+ * elements of the DMA-ordered weight buffer */
+int nbdt_conv_seg_info(void* plan, int32_t* tile, int32_t* nbuf, int32_t* steps, int32_t* max_rounds,
+                       int64_t* w_tile_elems);
+/* w[nmatrices] bf16 device pointers -> w_tiles (w_tile_elems bf16): per class, per cout tile, per K step one
+ * (32*NT rows) x 32 k tile stored as the swizzled LDS image it will be copied to */
+int nbdt_conv_seg_tile_weights(void* plan, const void* const* w, void* w_tiles, void* stream);
+/* in[ntensors] bf16 device pointers; residual (nullable) is addressed like class 0's output; bn_partials (nullable,
+ * single-class launches only) as in nbdt_conv_igemm_stats */
+int nbdt_conv_seg(void* plan, const void* const* in, const void* w_tiles, void* out, const void* residual,
+                  float* bn_partials, void* stream);
+/* host copy of one class's K-step records (8 int32 each: tap offset in halo pixels, halo buffer byte offset, LDS-DMA
+ * rounds issued in the step, their LDS destination, first halo pixel, channel, tensor, strict flag) and the number of
+ * slices its tiles load in their prologue -- so that the DMA schedule can be checked without a GPU.  Returns the
+ * number of steps (>= 0) or an error (< 0). */
+int nbdt_conv_seg_steps(void* plan, int32_t cls, int32_t* out8, int32_t max_steps, int32_t* npro);
+
 /* same launch, and the epilogue also writes the per-channel sum / sum of squares of the (bf16) output
  * of every 256-pixel tile to bn_partials[ceil(M/256)][2][cout] (plain stores, fully overwritten) -- the
  * statistics the following BatchNorm needs, so nbdt_bn_finalize can replace nbdt_bn_stats (no second
@@ -304,6 +370,13 @@ int nbdt_bn_finalize(int32_t B, int32_t H, int32_t W, int32_t C, float eps, floa
 int nbdt_bn_apply(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
                   const float* beta, const void* residual, int32_t relu, int32_t B, int32_t H,
                   int32_t W, int32_t C, void* y, void* stream);
+/* the same pass writing the SPACE-TO-DEPTH copy of its output: y is [B][H/2+2][W/2+2][4C] bf16 (zero border), input
+ * pixel (h, w) at pixel (h/2, w/2), channels [((h&1)*2 + (w&1))*C, +C).  What the stride-2 conv1 and the 1x1 stride-2
+ * shortcut of a shape-changing unit (and their weight gradients) read instead of the plain activated tensor:
+ * pytorchcv PreResUnit's shared pre-activation (nbdt/models/wideresnet.py:1-5), nbdt/models/resnet.py:56-67. */
+int nbdt_bn_apply_s2d(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                      const float* beta, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C, void* y,
+                      void* stream);
 /* backward, pass 1: with gy' = gy * mask when relu, writes dsum[0][c] = sum gy',
  * dsum[1][c] = sum gy' * xhat and accumulates dbeta += dsum[0], dgamma += dsum[1] (either may be
  * NULL).  mask = (y > 0) from the stored forward output y; with y == NULL (no residual in the
@@ -436,6 +509,9 @@ int nbdt_dropout_bwd(const float* gy, int64_t n, float p, const uint8_t* mask, f
 int nbdt_ref_conv(const nbdt_conv_desc* d, const float* in, const float* w, float* out, const float* residual,
                   void* stream);
 int nbdt_ref_wgrad(const nbdt_wgrad_desc* d, const float* x, const float* gy, float* dw, void* stream);
+/* twin of nbdt_conv_seg: fp32 tensors, fp32 weight matrices in their plain [cout][row_stride] layout (no tiling) */
+int nbdt_ref_conv_seg(void* plan, const float* const* in, const float* const* w, float* out, const float* residual,
+                      void* stream);
 /* partials == NULL: nbdt_bn_stats.  partials != NULL: the conv-epilogue form -- row 0 of bn_partials[rows][2][C]
  * receives sum / sum of squares, the other rows zero (nbdt_bn_finalize folds them as usual). */
 int nbdt_ref_bn_stats(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float eps, float momentum,
@@ -444,6 +520,9 @@ int nbdt_ref_bn_stats(const float* x, int32_t B, int32_t H, int32_t W, int32_t C
 int nbdt_ref_bn_apply(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
                       const float* beta, const float* residual, int32_t relu, int32_t B, int32_t H, int32_t W,
                       int32_t C, float* y, void* stream);
+int nbdt_ref_bn_apply_s2d(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                          const float* beta, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C, float* y,
+                          void* stream);
 /* nbdt_bn_bwd_reduce + nbdt_bn_bwd_apply (gy given) or nbdt_pool_bn_bwd_reduce + _apply (gy NULL, gpooled given);
  * reduce == 0: the elementwise pass only, with the caller's dsum */
 int nbdt_ref_bn_bwd(const float* gy, const float* gpooled, const float* y, const float* x, const float* save_mean,

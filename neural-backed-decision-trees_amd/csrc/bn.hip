@@ -728,6 +728,66 @@ extern "C" int nbdt_bn_apply(const void* x, const float* save_mean, const float*
   return NBDT_OK;
 }
 
+// y = [relu](bn(x)) written as the SPACE-TO-DEPTH copy the stride-2 convolutions of a shape-changing unit read
+// (csrc/conv_seg.hip): y is [B][H/2+2][W/2+2][4C]; input pixel (h, w) lands at pixel (h/2, w/2), channels
+// [((h&1)*2 + (w&1)) * C, +C).  Same arithmetic as bn_apply_kernel (the ReLU-mask recomputation of the backward
+// passes agrees), same bytes; nobody reads the activated tensor of such a unit in its plain layout.
+template <bool RELU>
+__global__ __launch_bounds__(kMaxThreads) void bn_apply_s2d_kernel(const bf16_t* __restrict__ x,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, PadGeom g, int c8,
+                                                                   int PY, bf16_t* __restrict__ y) {
+  const int cx = threadIdx.x % c8, py = threadIdx.x / c8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cx * 8 + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = beta[c] - mean[c] * sc[i];
+  }
+  const int row2 = (g.W / 2 + 2) * 4 * g.C, img2 = (g.H / 2 + 2) * row2;
+  for (int p = blockIdx.x * PY + py; p < g.npix; p += gridDim.x * PY) {
+    const unsigned t = fdiv((unsigned)p, g.div_w);
+    const int w = p - (int)t * g.W;
+    const unsigned b = fdiv(t, g.div_h);
+    const int h = (int)t - (int)b * g.H;
+    const int o = (int)b * g.img + (h + 1) * g.row + (w + 1) * g.C + cx * 8;
+    const int o2 = (int)b * img2 + ((h >> 1) + 1) * row2 + ((w >> 1) + 1) * 4 * g.C + ((h & 1) * 2 + (w & 1)) * g.C + cx * 8;
+    float f[8];
+    unpack8(*(const u32x4_t*)(x + o), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = f[i] * sc[i] + sh[i];
+      if (RELU) v = v > 0.f ? v : 0.f;
+      f[i] = v;
+    }
+    *(u32x4_t*)(y + o2) = pack8(f);
+  }
+}
+
+extern "C" int nbdt_bn_apply_s2d(const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                 const float* beta, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C, void* y,
+                                 void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && y, "null argument");
+  NBDT_REQUIRE(H % 2 == 0 && W % 2 == 0, "space-to-depth needs even H and W");
+  int rc = check_shape(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PadGeom g = make_geom(B, H, W, C);
+  const Layout l = layout_for(C);
+  const dim3 grid(grid_for(g, l, 8)), blk(l.threads);
+  if (relu)
+    hipLaunchKernelGGL((bn_apply_s2d_kernel<true>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma,
+                       beta, g, l.c8, l.py, (bf16_t*)y);
+  else
+    hipLaunchKernelGGL((bn_apply_s2d_kernel<false>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma,
+                       beta, g, l.c8, l.py, (bf16_t*)y);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
 extern "C" int nbdt_bn_bwd_reduce(const void* gy, const void* y, const void* x, const float* save_mean,
                                   const float* save_rstd, const float* gamma, const float* beta, int32_t relu,
                                   int32_t B, int32_t H, int32_t W, int32_t C, float* scratch, float* dsum,

@@ -292,6 +292,35 @@ extern "C" int nbdt_ref_bn_apply(const float* x, const float* save_mean, const f
   return NBDT_OK;
 }
 
+// twin of nbdt_bn_apply_s2d: y is the space-to-depth copy [B][H/2+2][W/2+2][4C]
+__global__ __launch_bounds__(256) void ref_bn_apply_s2d_kernel(const float* __restrict__ x, const float* mean,
+                                                               const float* rstd, const float* gamma, const float* beta,
+                                                               int relu, PadGeom g, float* __restrict__ y) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.npix * g.C) return;
+  const int c = (int)(idx % g.C), p = (int)(idx / g.C);
+  const int w = p % g.W, h = (p / g.W) % g.H, b = p / (g.W * g.H);
+  const int o = pad_offset(g, p) + c;
+  const long long row2 = (long long)(g.W / 2 + 2) * 4 * g.C, img2 = (g.H / 2 + 2) * row2;
+  const long long o2 = b * img2 + ((h >> 1) + 1) * row2 + ((w >> 1) + 1) * 4 * g.C + ((h & 1) * 2 + (w & 1)) * g.C + c;
+  const float sc = gamma[c] * rstd[c];
+  float v = x[o] * sc + (beta[c] - mean[c] * sc);
+  if (relu) v = v > 0.f ? v : 0.f;
+  y[o2] = v;
+}
+extern "C" int nbdt_ref_bn_apply_s2d(const float* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                     const float* beta, int32_t relu, int32_t B, int32_t H, int32_t W, int32_t C,
+                                     float* y, void* stream) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && y, "null argument");
+  NBDT_REQUIRE(H % 2 == 0 && W % 2 == 0, "space-to-depth needs even H and W");
+  const PadGeom g = make_geom(B, H, W, C);
+  const long long total = (long long)g.npix * C;
+  hipLaunchKernelGGL(ref_bn_apply_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, save_mean, save_rstd, gamma, beta, relu, g, y);
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
 /* whole BatchNorm(+ReLU) backward: sums (dsum, += dgamma, dbeta; reduce != 0) and the elementwise pass.  gy == NULL: the pooled head
  * (gy = gpooled[b][c] / (H*W)); y == NULL with relu: mask recomputed from x (needs beta). */
 extern "C" int nbdt_ref_bn_bwd(const float* gy, const float* gpooled, const float* y, const float* x,

@@ -51,6 +51,24 @@ class WgradDesc(ctypes.Structure):
     ]
 
 
+class ConvSegSlice(ctypes.Structure):
+    _fields_ = [("tensor", c_int32), ("ch0", c_int32), ("ntaps", c_int32), ("tap", c_int32 * 9),
+                ("w_matrix", c_int32), ("w_off", c_int32 * 9)]
+
+
+class ConvSegClass(ctypes.Structure):
+    _fields_ = [("nslices", c_int32), ("slices", POINTER(ConvSegSlice)),
+                ("out_bs", c_int32), ("out_hs", c_int32), ("out_ws", c_int32), ("out_base", c_int32)]
+
+
+class ConvSegDesc(ctypes.Structure):
+    _fields_ = [("B", c_int32), ("gh", c_int32), ("gw", c_int32), ("cout", c_int32),
+                ("ntensors", c_int32), ("pix_stride", c_int32 * 4),
+                ("nmatrices", c_int32), ("w_row_stride", c_int32 * 4),
+                ("nclasses", c_int32), ("cls", ConvSegClass * 4),
+                ("tile", c_int32), ("nbuf", c_int32)]
+
+
 _P = c_void_p
 _I32P = POINTER(c_int32)
 
@@ -88,6 +106,15 @@ SIGNATURES = {
     "nbdt_conv_igemm": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm_multi": (c_int, [_P, c_int32, _P, _P, _P, _P]),
     "nbdt_conv_igemm_stats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "nbdt_conv_seg_create": (c_int, [POINTER(ConvSegDesc), POINTER(c_void_p)]),
+    "nbdt_conv_seg_destroy": (c_int, [c_void_p]),
+    "nbdt_conv_seg_info": (c_int, [c_void_p, _I32P, _I32P, _I32P, _I32P, POINTER(c_int64)]),
+    "nbdt_conv_seg_steps": (c_int, [c_void_p, c_int32, _I32P, c_int32, _I32P]),
+    "nbdt_conv_seg_tile_weights": (c_int, [c_void_p, POINTER(c_void_p), _P, _P]),
+    "nbdt_conv_seg": (c_int, [c_void_p, POINTER(c_void_p), _P, _P, _P, _P, _P]),
+    "nbdt_ref_conv_seg": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P]),
+    "nbdt_bn_apply_s2d": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_ref_bn_apply_s2d": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_bn_finalize": (c_int, [c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nbdt_conv_igemm_affine": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int32, _P]),

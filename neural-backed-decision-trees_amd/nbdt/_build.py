@@ -25,6 +25,7 @@ FLAGS = {
     "conv.hip": ["-munsafe-fp-atomics"],
     "conv_dma.hip": ["-munsafe-fp-atomics"],
     "conv_halo.hip": ["-munsafe-fp-atomics"],
+    "conv_seg.hip": ["-munsafe-fp-atomics"],
     "wgrad.hip": ["-munsafe-fp-atomics"],
     "wgrad_dma.hip": ["-munsafe-fp-atomics"],
     "wgrad_taps.hip": ["-munsafe-fp-atomics"],

@@ -697,3 +697,188 @@ def dropout_fwd(x, p, seed, mask, y):
 
 def dropout_bwd(gy, p, mask, gx):
     check(lib().nbdt_dropout_bwd(ptr(gy), gy.numel(), p, ptr(mask), ptr(gx), stream_ptr(gy.device)))
+
+
+# ------------------------------------------------------------------------------------------------
+# slice-list convolutions (csrc/conv_seg.hip): the shape-changing units' convs as sums of stride-1 tap-subset convs
+
+class ConvSeg:
+    """A plan of nbdt_conv_seg_*: `classes` = [{"slices": [(tensor, ch0, [halo taps 3R+S], w_matrix, [w_off per tap])],
+    "out": (bs, hs, ws, base)}], over input tensors [B][gh+2][gw+2][pix_strides[i]] and weight matrices
+    [cout][w_row_strides[j]].  Host-side object; the device tables appear at the first launch."""
+
+    def __init__(self, B, gh, gw, cout, pix_strides, w_row_strides, classes, tile=0, nbuf=0, flops=None):
+        d = _C.ConvSegDesc()
+        d.B, d.gh, d.gw, d.cout = B, gh, gw, cout
+        d.ntensors, d.nmatrices, d.nclasses = len(pix_strides), len(w_row_strides), len(classes)
+        _fill(d.pix_stride, pix_strides)
+        _fill(d.w_row_stride, w_row_strides)
+        d.tile, d.nbuf = tile, nbuf
+        self._keep = []
+        for c, k in enumerate(classes):
+            arr = (_C.ConvSegSlice * len(k["slices"]))()
+            for s, (tensor, ch0, taps, wm, woffs) in enumerate(k["slices"]):
+                arr[s].tensor, arr[s].ch0, arr[s].ntaps, arr[s].w_matrix = tensor, ch0, len(taps), wm
+                _fill(arr[s].tap, taps)
+                _fill(arr[s].w_off, woffs)
+            self._keep.append(arr)
+            d.cls[c].nslices = len(k["slices"])
+            d.cls[c].slices = ctypes.cast(arr, ctypes.POINTER(_C.ConvSegSlice))
+            d.cls[c].out_bs, d.cls[c].out_hs, d.cls[c].out_ws, d.cls[c].out_base = k["out"]
+        self.desc, self.classes = d, classes
+        self.handle = ctypes.c_void_p()
+        check(lib().nbdt_conv_seg_create(ctypes.byref(d), ctypes.byref(self.handle)))
+        tile_, nbuf_, rounds = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        steps = (ctypes.c_int32 * 4)()
+        wel = ctypes.c_int64()
+        check(lib().nbdt_conv_seg_info(self.handle, ctypes.byref(tile_), ctypes.byref(nbuf_), steps, ctypes.byref(rounds),
+                                       ctypes.byref(wel)))
+        self.tile, self.nbuf, self.max_rounds, self.w_tile_elems = tile_.value, nbuf_.value, rounds.value, wel.value
+        self.nsteps = list(steps)[:len(classes)]
+        # algorithmic flops of a launch (the launch timers): 2 x pixels x cout x 32 per K step unless the caller knows better
+        self.flops = float(flops) if flops is not None else 2.0 * B * gh * gw * cout * 32 * sum(self.nsteps)
+
+    def steps(self, cls):
+        """(records [n][8] int32, prologue slices) of class `cls` -- host copy, no device work."""
+        import numpy as np
+        n = self.nsteps[cls]
+        buf = (ctypes.c_int32 * (8 * n))()
+        npro = ctypes.c_int32()
+        rc = lib().nbdt_conv_seg_steps(self.handle, cls, buf, n, ctypes.byref(npro))
+        if rc < 0:
+            check(rc)
+        return np.frombuffer(buf, dtype=np.int32).reshape(n, 8).copy(), npro.value
+
+    def tile_weights(self, ws, out=None):
+        """ws: the bf16 weight matrices -> the DMA-ordered tile buffer the launches read."""
+        dev = ws[0].device
+        if out is None:
+            out = torch.empty(self.w_tile_elems, dtype=torch.bfloat16, device=dev)
+        arr = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+        check(lib().nbdt_conv_seg_tile_weights(self.handle, arr, ptr(out), stream_ptr(dev)))
+        return out
+
+    def __call__(self, ins, w, out, residual=None, bn_scratch=None):
+        """w: the tile buffer (bf16 path) or, for fp32 tensors (verification-only reference mode), the list of fp32
+        weight matrices in their plain layout."""
+        dev = ins[0].device
+        arr = (ctypes.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+        if _ref(ins[0]):
+            warr = (ctypes.c_void_p * len(w))(*[t.data_ptr() for t in w])
+            check(lib().nbdt_ref_conv_seg(self.handle, arr, warr, ptr(out), ptr(residual), stream_ptr(dev)))
+            if bn_scratch is not None:
+                B, H, W, C = _dims(out)
+                check(lib().nbdt_ref_bn_stats(ptr(out), B, H, W, C, BN_EPS, BN_MOMENTUM, None, None, None, None,
+                                              ptr(bn_scratch), stream_ptr(dev)))
+            return
+        ev = None
+        if _timer is not None and _timer.wants("conv_igemm"):
+            ev = _timer.bracket("conv_igemm", self.flops, dev)
+            ev[0].record()
+        check(lib().nbdt_conv_seg(self.handle, arr, ptr(w), ptr(out), ptr(residual), ptr(bn_scratch), stream_ptr(dev)))
+        if ev is not None:
+            ev[1].record()
+            _timer.count(last_igemm_kernel())
+
+    def __del__(self):
+        try:
+            h = getattr(self, "handle", None)
+            if h is not None and h.value:
+                lib().nbdt_conv_seg_destroy(h)
+                self.handle = None
+        except Exception:      # (interpreter shutdown: modules may already be gone)
+            pass
+
+
+def _plain_out(H, W, C):
+    row = (W + 2) * C
+    return ((H + 2) * row, row, C, row + C)
+
+
+# 1-D phase tables of a stride-2 3x3 / pad-1 conv.  Forward over the space-to-depth input: phase p (row parity of the
+# input) holds kernel rows r with halo row R (input row y + R - 1 of the half-resolution grid): out(y) reads
+# in(2y + r - 1).  Data gradient: output parity p (of the unpadded input row) gets kernel rows r from gradient row u + R - 1.
+S2_FWD = {0: [(1, 1)], 1: [(0, 0), (2, 1)]}
+S2_BWD = {0: [(1, 1)], 1: [(0, 2), (2, 1)]}
+
+
+def _interleave(major, minor):
+    """`minor` slices spread evenly among `major` ones (never first: the first slice is every tile's prologue)."""
+    if not minor:
+        return list(major)
+    out, j = [], 0
+    for i, s in enumerate(major):
+        out.append(s)
+        while j < len(minor) and (j + 1) * len(major) <= (i + 1) * len(minor):
+            out.append(minor[j])
+            j += 1
+    out.extend(minor[j:])
+    return out
+
+
+def seg_fwd_s2(B, Hi, Wi, cin, cout, tile=0, nbuf=0, order=(3, 0, 1, 2)):
+    """Conv2d(3x3, stride 2, pad 1) forward over the space-to-depth copy [B][Hi/2+2][Wi/2+2][4 cin] of its input
+    (bn_apply_s2d); weight matrix 0 = the forward weights [cout][9][cin].  order: phases (2 p + q) per 32-channel chunk."""
+    Ho, Wo = Hi // 2, Wi // 2
+    slices = []
+    for kc in range(cin // 32):
+        for ph in order:
+            p, q = ph >> 1, ph & 1
+            taps = [(3 * R + S, 3 * r + s) for (r, R) in S2_FWD[p] for (s, S) in S2_FWD[q]]
+            slices.append((0, ph * cin + kc * 32, [t for t, _ in taps], 0, [w * cin + kc * 32 for _, w in taps]))
+    return ConvSeg(B, Ho, Wo, cout, [4 * cin], [9 * cin], [{"slices": slices, "out": _plain_out(Ho, Wo, cout)}],
+                   tile=tile, nbuf=nbuf, flops=2.0 * B * Ho * Wo * 9 * cin * cout)
+
+
+def seg_conv3x3_plus_1x1(B, H, W, cin, cout, cin_sc, sc_pix_stride, tile=0, nbuf=0):
+    """conv3x3(stride 1)(x) + conv1x1(s): tensor 0 = x [..][cin], tensor 1 = s with `sc_pix_stride` channels per pixel of
+    which the first cin_sc are the shortcut's input (the plain tensor, or phase (0,0) of a space-to-depth copy: a 1x1
+    stride-2 conv); matrices: [cout][9][cin], [cout][cin_sc]."""
+    major = [(0, kc * 32, list(range(9)), 0, [t * cin + kc * 32 for t in range(9)]) for kc in range(cin // 32)]
+    minor = [(1, kc * 32, [4], 1, [kc * 32]) for kc in range(cin_sc // 32)]
+    return ConvSeg(B, H, W, cout, [cin, sc_pix_stride], [9 * cin, cin_sc],
+                   [{"slices": _interleave(major, minor), "out": _plain_out(H, W, cout)}], tile=tile, nbuf=nbuf,
+                   flops=2.0 * B * H * W * cout * (9 * cin + cin_sc))
+
+
+def seg_dgrad_s2(B, Hi, Wi, cin, cout, shortcut=False, tile=0, nbuf=0):
+    """Data gradient of Conv2d(cin -> cout, 3x3, stride 2, pad 1) [+ of the 1x1 stride-2 shortcut next to it]: tensor 0 =
+    dL/d(conv output) [B][Hi/2+2][Wi/2+2][cout] (tensor 1 = dL/d(shortcut output), same shape); output dL/d(input)
+    [B][Hi+2][Wi+2][cin], every interior pixel written once (four parity classes); matrices: the transposed tap-reversed
+    copy wd [cin][9][cout] (weight_prep), and the shortcut's [cin][cout]."""
+    Ho, Wo = Hi // 2, Wi // 2
+    rowx = (Wi + 2) * cin
+    classes = []
+    for ph in (1, 0):
+        for pw in (1, 0):
+            taps = [(3 * R + S, 8 - (3 * r + s)) for (r, R) in S2_BWD[ph] for (s, S) in S2_BWD[pw]]
+            major = [(0, kc * 32, [t for t, _ in taps], 0, [w * cout + kc * 32 for _, w in taps])
+                     for kc in range(cout // 32)]
+            minor = [(1, kc * 32, [4], 1, [kc * 32]) for kc in range(cout // 32)] if (shortcut and ph == 0 and pw == 0) else []
+            classes.append({"slices": _interleave(major, minor),
+                            "out": ((Hi + 2) * rowx, 2 * rowx, 2 * cin, (ph + 1) * rowx + (pw + 1) * cin)})
+    return ConvSeg(B, Ho, Wo, cin, [cout, cout] if shortcut else [cout], [9 * cout, cout] if shortcut else [9 * cout],
+                   classes, tile=tile, nbuf=nbuf, flops=2.0 * B * Ho * Wo * cin * cout * (9 + (1 if shortcut else 0)))
+
+
+def seg_dgrad3x3_plus_1x1(B, H, W, cin, cout, tile=0, nbuf=0):
+    """Data gradient of conv3x3(cin -> cout, stride 1) plus that of the 1x1 shortcut beside it (stride 1): tensors
+    dL/d(conv output), dL/d(shortcut output) [B][H+2][W+2][cout]; matrices wd [cin][9][cout], wd_sc [cin][cout]."""
+    major = [(0, kc * 32, list(range(9)), 0, [t * cout + kc * 32 for t in range(9)]) for kc in range(cout // 32)]
+    minor = [(1, kc * 32, [4], 1, [kc * 32]) for kc in range(cout // 32)]
+    return ConvSeg(B, H, W, cin, [cout, cout], [9 * cout, cout],
+                   [{"slices": _interleave(major, minor), "out": _plain_out(H, W, cin)}], tile=tile, nbuf=nbuf,
+                   flops=2.0 * B * H * W * cin * cout * 10)
+
+
+def bn_apply_s2d(x, mean, rstd, gamma, beta, y, relu=True):
+    """y = [relu](bn(x)) as the space-to-depth copy [B][H/2+2][W/2+2][4C] (nbdt_bn_apply_s2d)."""
+    B, H, W, C = _dims(x)
+    fn = lib().nbdt_ref_bn_apply_s2d if _ref(x) else lib().nbdt_bn_apply_s2d
+    check(fn(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), 1 if relu else 0, B, H, W, C, ptr(y),
+             stream_ptr(x.device)))
+
+
+def s2d_buffer(B, H, W, C, device, dtype=torch.bfloat16):
+    """Zero-initialised space-to-depth activation buffer [B][H/2+2][W/2+2][4C] for an [H, W, C] tensor."""
+    return torch.zeros((B, H // 2 + 2, W // 2 + 2, 4 * C), dtype=dtype, device=device)

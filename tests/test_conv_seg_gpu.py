@@ -1,0 +1,231 @@
+"""Slice-list convolutions (csrc/conv_seg.hip) through the C-ABI against plain fp32 PyTorch on the same bf16-rounded
+inputs: the stride-2 3x3 forward over the space-to-depth input, conv3x3 + 1x1 shortcut in one launch, the four parity
+classes of the strided data gradient with the shortcut's data gradient folded in -- at small shapes that exercise every
+tile form (512 / 256 pixels, whole rows / whole images, 2 / 3 halo buffers, ragged last tile), and at the WRN-28-10
+shapes of the benched configuration at batch sizes the CPU reference finishes in seconds.
+
+Ops replaced: nbdt/models/resnet.py:56-67; pytorchcv PreResUnit (stride 2) behind nbdt/models/wideresnet.py:1-5."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from nbdt import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand_act(B, H, W, C, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16)
+    p = ops.padded(B, H, W, C, DEV)
+    ops.interior(p).copy_(x.to(DEV))
+    return x.float(), p
+
+
+def _rand_weight(cout, cin, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    wb = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(torch.bfloat16)
+    internal = wb.float().permute(0, 2, 3, 1).reshape(cout, k * k, cin).contiguous()
+    return wb.float(), internal.to(torch.bfloat16).to(DEV)
+
+
+def _close_bf16(got, ref, what):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = 2.0 ** -7 * ref.abs() + 2e-2 * ref.abs().mean() + 1e-6
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {(got - ref).abs().max():.4g}"
+
+
+def _border_zero(p):
+    t = p.float()
+    assert t[:, 0].abs().max() == 0 and t[:, -1].abs().max() == 0
+    assert t[:, :, 0].abs().max() == 0 and t[:, :, -1].abs().max() == 0
+
+
+def _s2d(xp_plain, B, H, W, C):
+    """space-to-depth copy of a padded tensor's interior, built with torch (what nbdt_bn_apply_s2d writes)."""
+    x = ops.interior(xp_plain)
+    y = ops.s2d_buffer(B, H, W, C, DEV)
+    yi = ops.interior(y)
+    for p in (0, 1):
+        for q in (0, 1):
+            yi[..., (2 * p + q) * C:(2 * p + q + 1) * C] = x[:, p::2, q::2, :]
+    return y
+
+
+def test_bn_apply_s2d_is_bn_apply_rearranged():
+    B, H, W, C = 3, 8, 16, 64
+    xf, xp = _rand_act(B, H, W, C, seed=1)
+    g = torch.Generator().manual_seed(2)
+    mean, rstd = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y = ops.padded(B, H, W, C, DEV)
+    ops.bn_apply(xp, mean, rstd, gamma, beta, y, relu=True)
+    y2 = ops.s2d_buffer(B, H, W, C, DEV)
+    ops.bn_apply_s2d(xp, mean, rstd, gamma, beta, y2, relu=True)
+    assert torch.equal(y2, _s2d(y, B, H, W, C))
+    _border_zero(y2)
+
+
+FWD_CASES = [   # B, Hi, Wi, cin, cout, tile, nbuf
+    (4, 16, 16, 64, 64, 0, 0),       # 8x8 out, NT=2
+    (8, 16, 16, 64, 64, 512, 2),     # forced 512-pixel tiles need 3 buffers here: refused below
+    (3, 32, 32, 32, 160, 0, 0),      # 16x16 out, NT=5, ragged (768 pixels: one and a half 512 tiles)
+    (16, 16, 16, 32, 128, 512, 3),   # 8x8 out, full tiles, NT=4
+    (2, 64, 64, 64, 32, 0, 0),       # 32x32 out, NT=1, row tiles
+    (5, 8, 8, 96, 160, 256, 3),      # 4x4 out: 16 images per half tile, ragged
+]
+
+
+@pytest.mark.parametrize("B,Hi,Wi,cin,cout,tile,nbuf", FWD_CASES)
+def test_strided_forward_over_space_to_depth(B, Hi, Wi, cin, cout, tile, nbuf):
+    xf, xp = _rand_act(B, Hi, Wi, cin, seed=1)
+    w_oihw, wb = _rand_weight(cout, cin, 3, seed=2)
+    Ho, Wo = Hi // 2, Wi // 2
+    if (tile, nbuf) == (512, 2):
+        with pytest.raises(Exception):
+            ops.seg_fwd_s2(B, Hi, Wi, cin, cout, tile=tile, nbuf=nbuf)
+        return
+    try:
+        plan = ops.seg_fwd_s2(B, Hi, Wi, cin, cout, tile=tile, nbuf=nbuf)
+    except Exception:
+        assert tile == 512 and Ho * Wo * 4 > 160     # (three halo buffers of a 512-pixel tile do not fit)
+        pytest.skip("shape does not fit the forced tile")
+    xs = _s2d(xp, B, Hi, Wi, cin)
+    wt = plan.tile_weights([wb])
+    out = ops.padded(B, Ho, Wo, cout, DEV)
+    plan([xs], wt, out)
+    ref = F.conv2d(xf.permute(0, 3, 1, 2), w_oihw, stride=2, padding=1).permute(0, 2, 3, 1)
+    _close_bf16(ops.interior(out), ref, "strided forward")
+    _border_zero(out)
+    # the same launch with the next BatchNorm's statistics: bit-identical output, partial rows that fold to the sums
+    out2 = ops.padded(B, Ho, Wo, cout, DEV)
+    M = B * Ho * Wo
+    scr = torch.full((((M + 255) // 256) * 2 * cout,), 7.0, device=DEV)
+    plan([xs], wt, out2, bn_scratch=scr)
+    assert torch.equal(out, out2)
+    part = scr.view(-1, 2, cout).sum(0).cpu()
+    o = ops.interior(out2).float().cpu().reshape(-1, cout)
+    torch.testing.assert_close(part[0], o.sum(0), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(part[1], (o * o).sum(0), rtol=1e-3, atol=1e-2)
+    # ... and with a residual
+    rf, rp = _rand_act(B, Ho, Wo, cout, seed=3)
+    out3 = ops.padded(B, Ho, Wo, cout, DEV)
+    plan([xs], wt, out3, residual=rp)
+    _close_bf16(ops.interior(out3), ref + rf, "strided forward + residual")
+
+
+PLUS_CASES = [   # B, H, W (output grid), cin2, cout, cin_sc, strided shortcut
+    (4, 8, 8, 64, 64, 32, True),
+    (3, 16, 16, 160, 160, 32, False),   # WRN stage-1 unit 1: 16(32) -> 160, plain shortcut input
+    (2, 16, 16, 320, 320, 160, True),   # WRN stage 2 unit 1
+    (9, 8, 8, 128, 128, 64, True),      # ragged
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,cin_sc,strided", PLUS_CASES)
+def test_conv3x3_plus_shortcut_in_one_launch(B, H, W, cin, cout, cin_sc, strided):
+    xf, xp = _rand_act(B, H, W, cin, seed=1)
+    w_oihw, wb = _rand_weight(cout, cin, 3, seed=2)
+    ws_oihw, wsb = _rand_weight(cout, cin_sc, 1, seed=3)
+    if strided:
+        sf, sp_plain = _rand_act(B, 2 * H, 2 * W, cin_sc, seed=4)
+        sp = _s2d(sp_plain, B, 2 * H, 2 * W, cin_sc)
+        sc_ref = F.conv2d(sf.permute(0, 3, 1, 2), ws_oihw, stride=2)
+        plan = ops.seg_conv3x3_plus_1x1(B, H, W, cin, cout, cin_sc, 4 * cin_sc)
+    else:
+        sf, sp = _rand_act(B, H, W, cin_sc, seed=4)
+        sc_ref = F.conv2d(sf.permute(0, 3, 1, 2), ws_oihw)
+        plan = ops.seg_conv3x3_plus_1x1(B, H, W, cin, cout, cin_sc, cin_sc)
+    wt = plan.tile_weights([wb, wsb.view(cout, cin_sc)])
+    out = ops.padded(B, H, W, cout, DEV)
+    M = B * H * W
+    scr = torch.zeros(((M + 255) // 256) * 2 * cout, device=DEV)
+    plan([xp, sp], wt, out, bn_scratch=scr)
+    ref = (F.conv2d(xf.permute(0, 3, 1, 2), w_oihw, padding=1) + sc_ref).permute(0, 2, 3, 1)
+    _close_bf16(ops.interior(out), ref, "conv3x3 + shortcut")
+    _border_zero(out)
+
+
+DGRAD_CASES = [   # B, Hi, Wi, cin, cout, shortcut
+    (4, 16, 16, 64, 64, True),
+    (4, 16, 16, 64, 64, False),
+    (3, 32, 32, 160, 320, True),     # WRN stage 2 unit 1 (16x16 gradient grid, ragged)
+    (8, 16, 16, 320, 640, True),     # WRN stage 3 unit 1 (8x8 gradient grid)
+    (2, 64, 64, 32, 64, True),       # 32x32 gradient grid, NT=1 output
+]
+
+
+@pytest.mark.parametrize("B,Hi,Wi,cin,cout,shortcut", DGRAD_CASES)
+def test_strided_data_gradient_classes(B, Hi, Wi, cin, cout, shortcut):
+    Ho, Wo = Hi // 2, Wi // 2
+    w_oihw, wb = _rand_weight(cout, cin, 3, seed=2)
+    ws_oihw, wsb = _rand_weight(cout, cin, 1, seed=3)
+    gf, gp = _rand_act(B, Ho, Wo, cout, seed=4)
+    g2f, g2p = _rand_act(B, Ho, Wo, cout, seed=5)
+    wd = wb.flip(1).permute(2, 1, 0).contiguous()            # [cin][9][cout], tap-reversed (what weight_prep builds)
+    wsd = wsb.view(cout, cin).t().contiguous()               # [cin][cout]
+    plan = ops.seg_dgrad_s2(B, Hi, Wi, cin, cout, shortcut=shortcut)
+    wt = plan.tile_weights([wd, wsd] if shortcut else [wd])
+    gx = ops.padded(B, Hi, Wi, cin, DEV)
+    ops.interior(gx).fill_(123.0)                              # every interior pixel must be overwritten
+    plan([gp, g2p] if shortcut else [gp], wt, gx)
+    x = torch.zeros(B, cin, Hi, Wi, requires_grad=True)
+    y = F.conv2d(x, w_oihw, stride=2, padding=1)
+    tot = (y * gf.permute(0, 3, 1, 2)).sum()
+    if shortcut:
+        tot = tot + (F.conv2d(x, ws_oihw, stride=2) * g2f.permute(0, 3, 1, 2)).sum()
+    tot.backward()
+    _close_bf16(ops.interior(gx), x.grad.permute(0, 2, 3, 1), "strided data gradient")
+    _border_zero(gx)
+
+
+def test_dense_data_gradient_plus_shortcut():
+    B, H, W, cin, cout = 3, 32, 32, 32, 160
+    w_oihw, wb = _rand_weight(cout, cin, 3, seed=2)
+    ws_oihw, wsb = _rand_weight(cout, cin, 1, seed=3)
+    gf, gp = _rand_act(B, H, W, cout, seed=4)
+    g2f, g2p = _rand_act(B, H, W, cout, seed=5)
+    wd = wb.flip(1).permute(2, 1, 0).contiguous()
+    wsd = wsb.view(cout, cin).t().contiguous()
+    plan = ops.seg_dgrad3x3_plus_1x1(B, H, W, cin, cout)
+    wt = plan.tile_weights([wd, wsd])
+    gx = ops.padded(B, H, W, cin, DEV)
+    plan([gp, g2p], wt, gx)
+    x = torch.zeros(B, cin, H, W, requires_grad=True)
+    tot = (F.conv2d(x, w_oihw, padding=1) * gf.permute(0, 3, 1, 2)).sum() + (F.conv2d(x, ws_oihw) * g2f.permute(0, 3, 1, 2)).sum()
+    tot.backward()
+    _close_bf16(ops.interior(gx), x.grad.permute(0, 2, 3, 1), "dense data gradient + shortcut")
+
+
+def test_fp32_twin_matches_torch():
+    """nbdt_ref_conv_seg (verification-only fp32 storage) on the same plans: 1e-5."""
+    B, Hi, Wi, cin, cout = 2, 16, 16, 32, 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Hi, Wi, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 17.0
+    xp = ops.padded(B, Hi, Wi, cin, DEV, torch.float32)
+    ops.interior(xp).copy_(x.to(DEV))
+    xs = ops.s2d_buffer(B, Hi, Wi, cin, DEV, torch.float32)
+    for p in (0, 1):
+        for q in (0, 1):
+            ops.interior(xs)[..., (2 * p + q) * cin:(2 * p + q + 1) * cin] = ops.interior(xp)[:, p::2, q::2, :]
+    plan = ops.seg_fwd_s2(B, Hi, Wi, cin, cout)
+    out = ops.padded(B, Hi // 2, Wi // 2, cout, DEV, torch.float32)
+    w_int = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(DEV)
+    plan([xs], [w_int], out)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, stride=2, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(ops.interior(out).cpu(), ref, rtol=1e-4, atol=1e-5)
+    # strided data gradient, four classes
+    gy = torch.randn(B, Hi // 2, Wi // 2, cout, generator=g)
+    gp = ops.padded(B, Hi // 2, Wi // 2, cout, DEV, torch.float32)
+    ops.interior(gp).copy_(gy.to(DEV))
+    wd = w.permute(0, 2, 3, 1).reshape(cout, 9, cin).flip(1).permute(2, 1, 0).contiguous().to(DEV)
+    dplan = ops.seg_dgrad_s2(B, Hi, Wi, cin, cout)
+    gx = ops.padded(B, Hi, Wi, cin, DEV, torch.float32)
+    dplan([gp], [wd.view(cin, 9 * cout)], gx)
+    xt = torch.zeros(B, cin, Hi, Wi, requires_grad=True)
+    (F.conv2d(xt, w, stride=2, padding=1) * gy.permute(0, 3, 1, 2)).sum().backward()
+    torch.testing.assert_close(ops.interior(gx).cpu(), xt.grad.permute(0, 2, 3, 1), rtol=1e-4, atol=1e-5)

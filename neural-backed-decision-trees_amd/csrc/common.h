@@ -23,7 +23,7 @@
      defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) ||                       \
      (defined(NBDT_HEAD_SKIP) && (NBDT_HEAD_SKIP + 0) != 0) || (defined(NBDT_PP_ABLATE) && (NBDT_PP_ABLATE + 0) != 0) || \
      (defined(NBDT_PP_SCHED) && (NBDT_PP_SCHED + 0) != 0) || (defined(NBDT_PP_TIMING) && (NBDT_PP_TIMING + 0) != 0) ||  \
-     (defined(NBDT_WPP_TIMING) && (NBDT_WPP_TIMING + 0) != 0) || (defined(NBDT_RULES_TIMING) && (NBDT_RULES_TIMING + 0) != 0))
+     (defined(NBDT_WPP_TIMING) && (NBDT_WPP_TIMING + 0) != 0) || (defined(NBDT_SEG_TIMING) && (NBDT_SEG_TIMING + 0) != 0) || (defined(NBDT_RULES_TIMING) && (NBDT_RULES_TIMING + 0) != 0))
 #error "timing-experiment switch without -DNBDT_TIMING_BUILD: these switches change what the kernels compute (csrc/common.h)"
 #endif
 #ifdef NBDT_TIMING_BUILD

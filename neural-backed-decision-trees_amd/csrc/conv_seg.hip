@@ -66,6 +66,24 @@ struct ConvSegParams {
 
 }  // namespace nbdt
 
+#ifndef NBDT_SEG_TIMING
+#define NBDT_SEG_TIMING 0      // 1: s_memtime stamps around the segments of every K step, per-(item, wave) sums in g_seg_timing
+#endif
+#if NBDT_SEG_TIMING
+__device__ unsigned g_seg_timing[8192 * 8];    // [item * 8 + wave][8]: load segment, barrier 1, MFMA segment, barrier 2, loop, steps, prologue, epilogue
+extern "C" int nbdt_debug_seg_timing(unsigned* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_seg_timing), sizeof(unsigned) * 8192 * 8);
+}
+__device__ __forceinline__ unsigned seg_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (unsigned)t;
+}
+#define NBDT_SEG_STAMP(acc_) { const unsigned t_ = seg_stamp(); acc_ += t_ - tm_prev; tm_prev = t_; }
+#else
+#define NBDT_SEG_STAMP(acc_)
+#endif
+
 __device__ __forceinline__ void seg_wait_vm(int n) {     // the n most recent LDS-DMA of this wave may stay in flight
   switch (n) {
 #define NBDT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
@@ -117,6 +135,11 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     const unsigned long long u = (unsigned long long)q;
     return (const bf16_t*)(((unsigned long long)NBDT_PIN((unsigned)(u >> 32)) << 32) | (unsigned)NBDT_PIN((unsigned)u));
   };
+  // (two input tensors: a step's source is one scalar select away -- an indexed load from the kernel-argument segment
+  //  in the MFMA segment put an s_waitcnt into the middle of the MFMA stream, a four-way select became branches)
+  const bf16_t* in0 = pin_ptr(p.in[0]);
+  const bf16_t* in1 = pin_ptr(p.in[1]);
+  const int ps0 = NBDT_PIN(p.pix_stride[0]), ps1 = NBDT_PIN(p.pix_stride[1]);
   const bf16_t* w_all = pin_ptr(p.w_tiles);
   typedef const __attribute__((address_space(4))) int* cint_ptr;       // constant address space: scalar loads
   const cint_ptr steps_all = (cint_ptr)(unsigned long long)p.steps;
@@ -241,8 +264,8 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     if (n > 0 && id0 + 8 * (n - 1) + wave >= a_instr) --n;
     q.n = n;
     q.strict = r.strict;
-    const int ps = p.pix_stride[r.pf_tensor];         // (kernel-argument segment, scalar loads by index)
-    q.src = p.in[r.pf_tensor] + r.pf_choff;
+    const int ps = r.pf_tensor ? ps1 : ps0;
+    q.src = (r.pf_tensor ? in1 : in0) + r.pf_choff;
     q.round_el = 128 * ps;
     q.dst = lds_base + r.pf_dst + wave * 1024;
     const int px0 = lp + (base_pix_w + r.pf_pix);
@@ -256,8 +279,8 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
 
   // ---- a tile's first LDS-DMA: its prologue slices (every piece) into buffers 0 .. npro-1, W(0), W(1)
   auto issue_slice = [&](int tensor, int choff, int base_pix, int buf) {
-    const int ps = p.pix_stride[tensor];
-    const bf16_t* src = p.in[tensor] + choff;
+    const int ps = tensor ? ps1 : ps0;
+    const bf16_t* src = (tensor ? in1 : in0) + choff;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
       const int id = wave + NWV * k;
@@ -291,12 +314,20 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
       for (int tm = 0; tm < MW; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
+#if NBDT_SEG_TIMING
+    const unsigned tm_top = seg_stamp();
+#endif
     Plan plan = prepare(load_step(steps, 0));
-    int prev_a = 0, prev_strict = 1;
+    int prev_a = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first DMA (and the last tile's stores)
     __builtin_amdgcn_s_barrier();            // bP: every wave's pieces have landed; the last epilogue's LDS is free
     if (grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if NBDT_SEG_TIMING
+    unsigned tm_l = 0, tm_b1 = 0, tm_m = 0, tm_b2 = 0;
+    const unsigned tm_begin = seg_stamp();
+    unsigned tm_prev = tm_begin;
+#endif
 
     // one K step with its weight tile in ring slot K (the ring position is the only literal left)
     auto step = [&](auto KC, int t) __attribute__((always_inline)) {
@@ -317,19 +348,42 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
       }
       // the weight pieces this wave issued one step ago must have landed; that step's halo pieces came after them in
       // issue order and may stay in flight unless the schedule marked them strict
-      if (prev_strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else seg_wait_vm(prev_a);
+      // (at most two stay in flight: a wider switch compiled to a tree of a dozen scalar branches per step)
+      // (hand-written: hipcc turns the three-way if into a dozen scalar instructions with mask registers)
+      asm volatile(
+          "s_cmp_lt_u32 %0, 2\n\t"
+          "s_cbranch_scc1 .Lseg_lt2_%=\n\t"
+          "s_waitcnt vmcnt(2)\n\t"
+          "s_branch .Lseg_done_%=\n"
+          ".Lseg_lt2_%=:\n\t"
+          "s_cmp_eq_u32 %0, 0\n\t"
+          "s_cbranch_scc1 .Lseg_0_%=\n\t"
+          "s_waitcnt vmcnt(1)\n\t"
+          "s_branch .Lseg_done_%=\n"
+          ".Lseg_0_%=:\n\t"
+          "s_waitcnt vmcnt(0)\n"
+          ".Lseg_done_%=:"
+          ::"s"(prev_a) : "memory", "scc");
       if (t + 2 < nsteps) issue_w(w_tiles, (K + 2) % 3, t + 2);
-#pragma unroll
-      for (int j = 0; j < MAXR - 1; ++j)
-        if (j < plan.n - 1) glds16_sf(plan.src + j * plan.round_el, plan.voff0, plan.dst + j * 8192);
-      if (plan.n > 0) glds16_sf(plan.src, plan.voffL, plan.dst + (plan.n - 1) * 8192);
-      prev_a = plan.n;
-      prev_strict = plan.strict;
+      if (plan.n > 0) {
+        glds16_sf(plan.src, plan.voffL, plan.dst + (plan.n - 1) * 8192);
+        const int m = plan.n - 1;       // rounds 0 .. m-1 share one lane offset; nested so that issuing is the fall-through path
+#define NBDT_ROUND(J) glds16_sf(plan.src + J * plan.round_el, plan.voff0, plan.dst + J * 8192)
+        if (__builtin_expect(m > 0, 1)) { NBDT_ROUND(0);
+          if (__builtin_expect(m > 1, 1)) { NBDT_ROUND(1);
+            if (m > 2) { NBDT_ROUND(2);
+              if (m > 3) { NBDT_ROUND(3);
+                if (m > 4) { NBDT_ROUND(4);
+                  if (m > 5) { NBDT_ROUND(5); } } } } } }
+#undef NBDT_ROUND
+      }
+      prev_a = plan.strict ? 0 : plan.n;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      NBDT_SEG_STAMP(tm_l)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      NBDT_SEG_STAMP(tm_b1)
       // ================= M(t): 2*MW*NT MFMAs; the idle issue slots between them prepare L(t+1) =================
       __builtin_amdgcn_s_setprio(1);
       plan = prepare(nrec);
@@ -349,9 +403,11 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
       asm volatile("" : "+v"(plan.ra[0][0]), "+v"(plan.ra[1][0]), "+v"(plan.voff0), "+v"(plan.voffL));
       if (MW == 2) asm volatile("" : "+v"(plan.ra[0][MW - 1]), "+v"(plan.ra[1][MW - 1]));
       __builtin_amdgcn_s_setprio(0);
+      NBDT_SEG_STAMP(tm_m)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      NBDT_SEG_STAMP(tm_b2)
     };
     for (int t = 0; t < nsteps; t += 3) {
       step(std::integral_constant<int, 0>{}, t);
@@ -364,7 +420,19 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     // ---- epilogue with the class's own output map
     nbdt::ConvDmaParams pc = p.c;
     pc.d.out_bs = cur.out_bs; pc.d.out_hs = cur.out_hs; pc.d.out_ws = cur.out_ws; pc.d.out_base = cur.out_base;
+#if NBDT_SEG_TIMING
+    const unsigned tm_epi = seg_stamp();
+#endif
     conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, pc, epi_lds, m0, n0, m_blk, wave, lane, tid);
+#if NBDT_SEG_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const int gi = ((bid & 7) * p.tiles_per_xcd * p.ncls + li) & 1023;      // (XCD-major item index, first 1024)
+      unsigned* o = g_seg_timing + (gi * 8 + wave) * 8;
+      o[0] = tm_l; o[1] = tm_b1; o[2] = tm_m; o[3] = tm_b2; o[4] = tm_epi - tm_begin; o[5] = nsteps;
+      o[6] = tm_begin - tm_top; o[7] = seg_stamp() - tm_epi;
+    }
+#endif
 
     const int next = li + nl;
     if (next >= n_items) break;

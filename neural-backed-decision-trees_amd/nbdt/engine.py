@@ -18,7 +18,7 @@ import math
 
 import torch
 
-from nbdt import ops
+from nbdt import _C, ops
 
 SIDE_STREAM_PRIORITY = 0       # HIP stream priority of the weight-gradient stream (A/B: scratch/ab_stream_priority.py)
 
@@ -179,6 +179,32 @@ class Conv:
         for d in descs:
             ops.conv_igemm(d, gout, self._wd_for(gout), gin)
 
+    def s2d_plan(self, B, Hi, Wi):
+        """(forward desc [1x1 only], wgrad desc) of this stride-2 conv over the space-to-depth copy of its input."""
+        key = ("s2d", B, Hi, Wi)
+        if key not in self._plans:
+            fwd = ops.conv_fwd_desc_s2d_1x1(B, Hi, Wi, self.cin, self.cout) if self.k == 1 else None
+            wg = ops.conv_wgrad_desc_s2d(B, Hi, Wi, self.cin, self.cout, self.k)
+            for d in (fwd, wg):
+                if d is not None:
+                    d.flop_channels = (self.cin_real, self.cout_real)
+            self._plans[key] = (fwd, wg)
+        return self._plans[key]
+
+    def forward_s2d(self, xs, out, Hi, Wi):
+        ops.conv_igemm(self.s2d_plan(xs.shape[0], Hi, Wi)[0], xs, self._w_for(xs), out)
+
+    def backward_weight_s2d(self, xs, gout, Hi, Wi):
+        desc = self.s2d_plan(xs.shape[0], Hi, Wi)[1]
+        side = getattr(self, "side_stream", None)
+        if side is None:
+            ops.conv_wgrad(desc, xs, gout, self.store.g(self.name))
+            return
+        main = torch.cuda.current_stream(xs.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(desc, xs, gout, self.store.g(self.name))
+
     def backward_weight(self, x, gout, cu_budget=0):
         """cu_budget: CUs this launch is sized for when it runs on the second stream (0 = all of them): the caller
         is about to launch an HBM-bound pass on the main stream that should get the remaining CUs."""
@@ -193,6 +219,26 @@ class Conv:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ops.conv_wgrad(self.plan(B, Hp - 2, Wp - 2)[3], x, gout, self.store.g(self.name), cu_budget)
+
+
+class SegOp:
+    """A slice-list launch (ops.ConvSeg, csrc/conv_seg.hip) together with its DMA-ordered weight tiles.  `sources` returns
+    the bf16 weight matrices the tiles are built from (views of the engine's flat bf16 mirror / data-gradient copies) and
+    `sources32` their fp32 twins for the verification-only reference mode; `on_side`: the sources are the data-gradient
+    copies the engine builds on its second stream, so the tiles are built there too."""
+
+    def __init__(self, plan, sources, sources32, on_side):
+        self.plan, self.sources, self.sources32, self.on_side = plan, sources, sources32, on_side
+        self.tiles = None
+
+    def retile(self):
+        self.tiles = self.plan.tile_weights(self.sources(), out=self.tiles)
+
+    def __call__(self, ins, out, bn_scratch=None):
+        if ins[0].dtype == torch.float32:
+            self.plan(ins, self.sources32(), out, bn_scratch=bn_scratch)
+        else:
+            self.plan(ins, self.tiles, out, bn_scratch=bn_scratch)
 
 
 class BatchNorm:
@@ -296,6 +342,37 @@ class _Engine:
         self._share_calibrated = True
         self.cu_share_report = None
         self._overlap = True
+        self.use_seg = True       # shape-changing units on the slice-list kernel (conv_seg.hip); False: rounds 1-5's launches
+        self._seg_ops = {}
+
+    def seg_op(self, key, build, sources, sources32, on_side=False):
+        """The SegOp `key` (created, and its weights tiled, at first use: a new batch size or image size)."""
+        op = self._seg_ops.get(key)
+        if op is None:
+            op = SegOp(build(), sources, sources32, on_side)
+            if self.act_dtype != torch.float32:
+                if on_side and self._side is not None and self._overlap:
+                    self._side.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(self._side):
+                        op.retile()
+                    torch.cuda.current_stream(self.device).wait_stream(self._side)
+                else:
+                    op.retile()
+            self._seg_ops[key] = op
+        return op
+
+    def _retile_seg(self, on_side):
+        if self.act_dtype == torch.float32:
+            return
+        for op in self._seg_ops.values():
+            if op.on_side == on_side:
+                op.retile()
+
+    def s2d_buf(self, key, B, H, W, C):
+        k = (key, "s2d", B, H, W, C)
+        if k not in self._bufs:
+            self._bufs[k] = ops.s2d_buffer(B, H, W, C, self.device, self.act_dtype)
+        return self._bufs[k]
 
     def scratch(self, C):
         need = ops.BN_SLOTS * 2 * C
@@ -365,6 +442,8 @@ class _Engine:
         self.act_dtype = torch.float32 if on else torch.bfloat16
         self.fuse_eval = not on
         self._bufs = {}
+        self._seg_ops = {}
+        self.__dict__.pop("_seg_skip", None)
         for c in self.convs:
             c._plans = {}
         self._share_calibrated = True        # (a timing decision between two schedules of the SLOW kernels means nothing)
@@ -623,10 +702,12 @@ class _Engine:
                 c.wd32 = self.store.p(c.name).flip(1).permute(2, 1, 0).contiguous()
         if self._wt_n:     # forward tiles are needed by the very next forward: caller's stream
             ops.weight_tile_batched(self.store.bf16, self._wt_ftable, self._wt_n, self._wt_ftotal, self._wt_fwd)
+        self._retile_seg(False)
         if self._side is None or not getattr(self, "_overlap", True):
             ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
             if self._wt_n:
                 ops.weight_tile_batched(self._wd_flat, self._wt_dtable, self._wt_n, self._wt_dtotal, self._wt_dgrad)
+            self._retile_seg(True)
             return
         # the transposed copies are only read by data-gradient launches: build them on the second stream while
         # the next forward runs (backward() joins the stream before its first dgrad)
@@ -635,6 +716,7 @@ class _Engine:
             ops.weight_prep_batched(self.store.flat, self._wd_table, len(self.convs), self._wd_total, self._wd_flat)
             if self._wt_n:
                 ops.weight_tile_batched(self._wd_flat, self._wt_dtable, self._wt_n, self._wt_dtotal, self._wt_dgrad)
+            self._retile_seg(True)
 
     def sgd_step(self, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, zero_grad=False):
         """optim.SGD step over every parameter (main.py:207) + refresh of bf16 / dgrad weights.
@@ -753,6 +835,47 @@ class WRNEngine(_Engine):
         # calibration before the first backward() finds it faster on this box (set_cu_share(None) turns it off)
         self.set_cu_share(47.0)
 
+    # ---- the shape-changing units on the slice-list kernel (csrc/conv_seg.hip)
+    def _seg_conv1(self, u, B, h, w):
+        """stride-2 conv1 forward over the space-to-depth a1."""
+        c = u["conv1"]
+        return self.seg_op((u["key"], "conv1", B, h, w), lambda: ops.seg_fwd_s2(B, h, w, c.cin, c.cout),
+                           lambda: [self.store.pb(c.name).view(c.cout, 9 * c.cin)],
+                           lambda: [self.store.p(c.name).view(c.cout, 9 * c.cin)])
+
+    def _seg_conv2_sc(self, u, B, ho, wo):
+        """conv2 + shortcut in one launch (the residual add disappears into the K loop); None where the plan would fall
+        back to 256-pixel half tiles (8x8 grids cannot hold three halo buffers of a 512-pixel tile: the dense kernel + a
+        separate 1x1 launch are faster there; engine.seg_fuse_half_tiles = True fuses anyway, A/B)."""
+        c2, ci = u["conv2"], u["idconv"]
+        key = (u["key"], "conv2sc", B, ho, wo)
+        if key in self._seg_ops:
+            return self._seg_ops[key]
+        skip = self.__dict__.setdefault("_seg_skip", set())
+        if key in skip:
+            return None
+        try:
+            plan = ops.seg_conv3x3_plus_1x1(B, ho, wo, c2.cin, c2.cout, ci.cin, (4 if u["stride"] == 2 else 1) * ci.cin)
+        except _C.NBDTHipError:
+            plan = None
+        if plan is None or (plan.tile != 512 and not getattr(self, "seg_fuse_half_tiles", False)):
+            skip.add(key)
+            return None
+        return self.seg_op(key, lambda: plan,
+                           lambda: [self.store.pb(c2.name).view(c2.cout, 9 * c2.cin), self.store.pb(ci.name).view(ci.cout, ci.cin)],
+                           lambda: [self.store.p(c2.name).view(c2.cout, 9 * c2.cin), self.store.p(ci.name).view(ci.cout, ci.cin)])
+
+    def _seg_dgrad(self, u, B, hi, wi):
+        """dL/d(a1) = conv1's data gradient (four parity classes when strided) + the shortcut's, one launch."""
+        c1, ci = u["conv1"], u["idconv"]
+        if u["stride"] == 2:
+            build = lambda: ops.seg_dgrad_s2(B, hi, wi, c1.cin, c1.cout, shortcut=True)
+        else:
+            build = lambda: ops.seg_dgrad3x3_plus_1x1(B, hi, wi, c1.cin, c1.cout)
+        return self.seg_op((u["key"], "dgrad", B, hi, wi), build,
+                           lambda: [c1.wd.view(c1.cin, 9 * c1.cout), ci.wd.view(ci.cin, ci.cout)],
+                           lambda: [c1.wd32.view(c1.cin, 9 * c1.cout), ci.wd32.view(ci.cin, ci.cout)], on_side=True)
+
     def _calibration_unit(self):
         for u in self.units:      # a widest-tensor unit without a shape change: both of its convs are dense 3x3
             if u["idconv"] is None and u["cout"] == self.units[0]["cout"]:
@@ -778,26 +901,46 @@ class WRNEngine(_Engine):
             k, s = u["key"], u["stride"]
             cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
             ho, wo = h // s, w // s
-            a1 = self.buf(k + ".a1", B, h, w, cin)
             t = self.buf(k + ".t", B, ho, wo, cout)
             a2 = self.buf(k + ".a2", B, ho, wo, cout)
             out = self.buf(k + ".out", B, ho, wo, cout)
             fuse = training and self.fuse_stats
             u["bn1"].stats(x, training, fused=fuse and x_has_stats)
-            u["bn1"].apply(x, a1, relu=True)
+            # Shape-changing units in training mode (round 6, csrc/conv_seg.hip): the pre-activation of a stride-2 unit is
+            # written as its space-to-depth copy -- its only readers are conv1, the shortcut and their weight gradients,
+            # all stride 2 -- conv1 runs as a slice list over it, and conv2 takes the shortcut as one more term of its K
+            # loop (no shortcut launch, no residual read in the epilogue).
+            seg = training and self.use_seg and u["idconv"] is not None
+            u["seg"] = seg
+            if seg and s == 2:
+                a1 = self.s2d_buf(k + ".a1", B, h, w, cin)
+                ops.bn_apply_s2d(x, u["bn1"].mean, u["bn1"].rstd, u["bn1"].gamma, u["bn1"].beta, a1, relu=True)
+            else:
+                a1 = self.buf(k + ".a1", B, h, w, cin)
+                u["bn1"].apply(x, a1, relu=True)
             if not training and self.fuse_eval:   # conv1 + bn2 + ReLU in one launch (t is never materialised)
                 u["conv1"].forward_affine(a1, a2, u["bn2"], act=1)
             else:
-                u["conv1"].forward(a1, t, bn_scratch=self.partials(t) if fuse else None)
+                if seg and s == 2:
+                    self._seg_conv1(u, B, h, w)([a1], t, bn_scratch=self.partials(t) if fuse else None)
+                else:
+                    u["conv1"].forward(a1, t, bn_scratch=self.partials(t) if fuse else None)
                 u["bn2"].stats(t, training, fused=fuse)
                 u["bn2"].apply(t, a2, relu=True)
-            if u["idconv"] is not None:
-                idn = self.buf(f"idn{cout}", B, ho, wo, cout)
-                u["idconv"].forward(a1, idn)
-                res = idn
+            both = self._seg_conv2_sc(u, B, ho, wo) if seg else None
+            if both is not None:
+                both([a2, a1], out, bn_scratch=self.partials(out) if fuse else None)
             else:
-                res = x
-            u["conv2"].forward(a2, out, residual=res, bn_scratch=self.partials(out) if fuse else None)
+                if u["idconv"] is not None:
+                    idn = self.buf(f"idn{cout}", B, ho, wo, cout)
+                    if seg and s == 2:
+                        u["idconv"].forward_s2d(a1, idn, h, w)
+                    else:
+                        u["idconv"].forward(a1, idn)
+                    res = idn
+                else:
+                    res = x
+                u["conv2"].forward(a2, out, residual=res, bn_scratch=self.partials(out) if fuse else None)
             x_has_stats = True
             u["x_in"], u["x_out"] = x, out
             x, h, w = out, ho, wo
@@ -872,7 +1015,8 @@ class WRNEngine(_Engine):
             cin, cout = _pad32(u["cin"]), _pad32(u["cout"])
             ho, wo = h, w
             hi, wi = ho * s, wo * s
-            a1 = self.buf(k + ".a1", B, hi, wi, cin)
+            seg = bool(u.get("seg"))
+            a1 = self.s2d_buf(k + ".a1", B, hi, wi, cin) if (seg and s == 2) else self.buf(k + ".a1", B, hi, wi, cin)
             t = self.buf(k + ".t", B, ho, wo, cout)
             a2 = self.buf(k + ".a2", B, ho, wo, cout)
             tag = ("@" + k) if self.debug_keep else ""
@@ -935,6 +1079,23 @@ class WRNEngine(_Engine):
                 n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 4) if share else 0
                 u["bn1"].backward_fused(ga1, x_in, g_in, self.partials(x_in), gx_add=g, cus=n1)
                 g, h, w = g_in, hi, wi
+                continue
+            if seg:
+                # conv1's and the shortcut's data gradients in one launch (strided: the four parity classes, the
+                # shortcut's gradient one more term of the even/even class); weight gradients read the same a1
+                if s == 2:
+                    u["conv1"].backward_weight_s2d(a1, gt, hi, wi)
+                    u["idconv"].backward_weight_s2d(a1, g, hi, wi)
+                else:
+                    u["conv1"].backward_weight(a1, gt)
+                    u["idconv"].backward_weight(a1, g)
+                self._seg_dgrad(u, B, hi, wi)([gt, g], ga1)
+                u["bn1"].backward(ga1, None, u["x_in"], g_in, relu=True)
+                g, h, w = g_in, hi, wi
+                if comm is not None and u["key"] in ("s3u1", "s2u1"):
+                    self.join_side_stream()
+                    comm.reduce_range(st.grad, *buckets[0 if u["key"] == "s3u1" else 1])
+                    self._reserve_for(comm)
                 continue
             u["conv1"].backward_weight(a1, gt)
             u["conv1"].backward_data(gt, ga1)

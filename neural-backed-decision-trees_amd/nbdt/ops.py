@@ -882,3 +882,50 @@ def bn_apply_s2d(x, mean, rstd, gamma, beta, y, relu=True):
 def s2d_buffer(B, H, W, C, device, dtype=torch.bfloat16):
     """Zero-initialised space-to-depth activation buffer [B][H/2+2][W/2+2][4C] for an [H, W, C] tensor."""
     return torch.zeros((B, H // 2 + 2, W // 2 + 2, 4 * C), dtype=dtype, device=device)
+
+
+def conv_wgrad_desc_s2d(B, Hi, Wi, cin, cout, k):
+    """Weight gradient of Conv2d(k in {1,3}, stride 2, pad k//2) when its input is stored as the space-to-depth copy
+    [B][Hi/2+2][Wi/2+2][4 cin] (bn_apply_s2d): tap (r, s) reads phase (r != 1, s != 1) at half-resolution pixel
+    (y + (r == 0 ? -1 : 0), x + ...) -- every tap a unit-stride pixel walk of 4 cin-element pixels."""
+    Ho, Wo = Hi // 2, Wi // 2
+    d = WgradDesc()
+    d.B, d.gh, d.gw, d.cin, d.cout = B, Ho, Wo, cin, cout
+    row2 = (Wo + 2) * 4 * cin
+    if k == 3:
+        d.ntaps = d.w_ntaps = 9
+        offs = []
+        for r in range(3):
+            for s in range(3):
+                p, q = int(r != 1), int(s != 1)
+                dy, dx = (-1 if r == 0 else 0), (-1 if s == 0 else 0)
+                offs.append((1 + dy) * row2 + (1 + dx) * 4 * cin + (2 * p + q) * cin)
+        _fill(d.tap_off, offs)
+        _fill(d.w_tap, range(9))
+        d.x_base = 0
+    else:
+        d.ntaps = d.w_ntaps = 1
+        d.tap_off[0] = 0
+        d.w_tap[0] = 0
+        d.x_base = row2 + 4 * cin
+    d.x_bs, d.x_hs, d.x_ws = (Ho + 2) * row2, row2, 4 * cin
+    rowo = (Wo + 2) * cout
+    d.g_bs, d.g_hs, d.g_ws, d.g_base = (Ho + 2) * rowo, rowo, cout, rowo + cout
+    return d
+
+
+def conv_fwd_desc_s2d_1x1(B, Hi, Wi, cin, cout):
+    """Conv2d(1x1, stride 2) forward over the space-to-depth copy of its input: phase (0, 0), unit-stride pixels."""
+    Ho, Wo = Hi // 2, Wi // 2
+    d = ConvDesc()
+    d.B, d.gh, d.gw, d.cin, d.cout = B, Ho, Wo, cin, cout
+    row2 = (Wo + 2) * 4 * cin
+    d.ntaps = d.w_ntaps = 1
+    d.tap_off[0] = 0
+    d.w_tap[0] = 0
+    d.in_bs, d.in_hs, d.in_ws, d.in_base = (Ho + 2) * row2, row2, 4 * cin, row2 + 4 * cin
+    rowo = (Wo + 2) * cout
+    d.out_bs, d.out_hs, d.out_ws, d.out_base = (Ho + 2) * rowo, rowo, cout, rowo + cout
+    d.accumulate = 0
+    d.wide_tile = 1
+    return d

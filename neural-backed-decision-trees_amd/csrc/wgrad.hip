@@ -7,6 +7,7 @@
 // 2^19) and both operands are channel-contiguous, so one of them must be transposed on the way to the MFMA: the
 // kernels stage [pixel][channel] tiles in LDS by LDS-DMA and read them back with ds_read_b64_tr_b16.
 //   wgrad_taps.hip  dense 3x3 / stride-1 convs: one block owns all nine taps of a (cout, cin) tile
+//   wgrad_s2d.hip   3x3 / stride-2 convs over the space-to-depth copy of their input: all nine taps, four phase sub-tiles
 //   wgrad_dma.hip   every other shape: one block per (tap, cout tile, cin tile)
 // Partial sums over the pixel splits are combined with fp32 atomics (+= semantics).  Roofline: MFMA-bound,
 // flops = 2*M*cout*ntaps*cin per launch.
@@ -31,7 +32,9 @@ extern "C" int nbdt_conv_wgrad(const nbdt_wgrad_desc* d, const void* x, const vo
   const int64_t M_all = (int64_t)d->B * d->gh * d->gw;
   NBDT_REQUIRE(M_all < (1ll << 31), "pixel grid too large");
   if (nbdt::wgrad_taps_applicable(d)) return nbdt::wgrad_taps(d, x, gy, dw, (hipStream_t)stream);
-  NBDT_REQUIRE(d->variant == 0, "variant 2 / 3 select between the dense 3x3 stride-1 kernels only");
+  // 3x3 stride-2 over the space-to-depth copy of the input (round 6; variant 3 = the first-generation kernel, A/B and tests)
+  if (d->variant != 3 && nbdt::wgrad_s2d_applicable(d)) return nbdt::wgrad_s2d(d, x, gy, dw, (hipStream_t)stream);
+  NBDT_REQUIRE(d->variant == 0 || d->variant == 3, "variant 2 / 4 / 5 select between the dense 3x3 stride-1 kernels only");
   nbdt::g_last_wgrad = "conv_wgrad_dma_kernel";
   return nbdt::wgrad_dma(d, x, gy, dw, (hipStream_t)stream);
 }

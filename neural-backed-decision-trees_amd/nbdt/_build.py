@@ -29,6 +29,7 @@ FLAGS = {
     "wgrad.hip": ["-munsafe-fp-atomics"],
     "wgrad_dma.hip": ["-munsafe-fp-atomics"],
     "wgrad_taps.hip": ["-munsafe-fp-atomics"],
+    "wgrad_s2d.hip": ["-munsafe-fp-atomics"],
     "bn.hip": ["-munsafe-fp-atomics"],
     "misc.hip": ["-munsafe-fp-atomics"],
     "effnet.hip": ["-munsafe-fp-atomics"],

@@ -92,3 +92,18 @@ if 'first' in which:
         ops.conv_igemm(dd, g, w1d, gx)
         ops.conv_igemm(ds, g2, wsd, gx)
     report("s1u1 dgrad+sc 32x32 160->32", plan.flops, timeit(lambda: plan([g, g2], wt, gx)), timeit(old), plan)
+
+if 'wgrad' in which:
+    for (Hi, cin, cout) in [(32, 160, 320), (16, 320, 640)]:
+        Ho = Hi // 2
+        xs = ops.s2d_buffer(B, Hi, Hi, cin, DEV); ops.interior(xs).normal_()
+        x = act(Hi, cin); g = act(Ho, cout)
+        dw = torch.zeros(cout, 9, cin, device=DEV)
+        dn = ops.conv_wgrad_desc_s2d(B, Hi, Hi, cin, cout, 3)
+        d3 = ops.conv_wgrad_desc_s2d(B, Hi, Hi, cin, cout, 3); d3.variant = 3
+        do = ops.conv_wgrad_desc(B, Hi, Hi, cin, cout, 3, 2)
+        fl = 2.0 * B * Ho * Ho * 9 * cin * cout
+        tn = timeit(lambda: ops.conv_wgrad(dn, xs, g, dw)); k = ops.last_wgrad_kernel()
+        t3 = timeit(lambda: ops.conv_wgrad(d3, xs, g, dw))
+        to = timeit(lambda: ops.conv_wgrad(do, x, g, dw))
+        print(f"wgrad s2 {Hi}x{Hi} {cin}->{cout}: {k} {tn*1e6:6.1f} us {fl/tn/1e12:5.0f} TF ({fl/tn/2.5e15:.3f})   wgrad_dma on s2d {t3*1e6:6.1f} us   wgrad_dma plain {to*1e6:6.1f} us", flush=True)

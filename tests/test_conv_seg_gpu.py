@@ -229,3 +229,59 @@ def test_fp32_twin_matches_torch():
     xt = torch.zeros(B, cin, Hi, Wi, requires_grad=True)
     (F.conv2d(xt, w, stride=2, padding=1) * gy.permute(0, 3, 1, 2)).sum().backward()
     torch.testing.assert_close(ops.interior(gx).cpu(), xt.grad.permute(0, 2, 3, 1), rtol=1e-4, atol=1e-5)
+
+
+WGRAD_CASES = [   # B, Hi, Wi, cin, cout  (half-resolution grid Hi/2 x Wi/2; the new kernel needs >= 4096 output pixels)
+    (16, 32, 32, 64, 160),     # 16x16 grid, WM = 5, two cin blocks
+    (64, 16, 16, 32, 128),     # 8x8 grid, WM = 4
+    (4, 64, 64, 32, 64),       # 32x32 grid: stages of 2 x 32, WM = 2
+    (17, 32, 32, 32, 32),      # 16x16 grid, WM = 1, a pixel count that does not divide by the split
+]
+
+
+@pytest.mark.parametrize("B,Hi,Wi,cin,cout", WGRAD_CASES)
+def test_strided_weight_gradient_over_space_to_depth(B, Hi, Wi, cin, cout):
+    Ho, Wo = Hi // 2, Wi // 2
+    xf, xp = _rand_act(B, Hi, Wi, cin, seed=1)
+    gf, gp = _rand_act(B, Ho, Wo, cout, seed=2)
+    xs = _s2d(xp, B, Hi, Wi, cin)
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    (F.conv2d(xf.permute(0, 3, 1, 2), w, stride=2, padding=1) * gf.permute(0, 3, 1, 2)).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(cout, 9, cin)
+    d = ops.conv_wgrad_desc_s2d(B, Hi, Wi, cin, cout, 3)
+    dw = torch.zeros(cout, 9, cin, device=DEV)
+    ops.conv_wgrad(d, xs, gp, dw)
+    assert ops.last_wgrad_kernel() == "conv_wgrad_s2d_kernel"
+    tol = dict(rtol=2e-3, atol=2e-3 * ref.abs().mean().item())
+    torch.testing.assert_close(dw.cpu(), ref, **tol)
+    ops.conv_wgrad(d, xs, gp, dw)                     # += semantics
+    torch.testing.assert_close(dw.cpu(), 2 * ref, rtol=2e-3, atol=4e-3 * ref.abs().mean().item())
+    # the first-generation kernel on the same descriptor (variant 3), and both in deterministic mode: same sums
+    d3 = ops.conv_wgrad_desc_s2d(B, Hi, Wi, cin, cout, 3)
+    d3.variant = 3
+    dw3 = torch.zeros(cout, 9, cin, device=DEV)
+    ops.conv_wgrad(d3, xs, gp, dw3)
+    assert ops.last_wgrad_kernel() == "conv_wgrad_dma_kernel"
+    torch.testing.assert_close(dw3.cpu(), ref, **tol)
+    ops.set_deterministic(True)
+    try:
+        a, b = torch.zeros_like(dw), torch.zeros_like(dw)
+        ops.conv_wgrad(d, xs, gp, a)
+        ops.conv_wgrad(d, xs, gp, b)
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a.cpu(), ref, **tol)
+    finally:
+        ops.set_deterministic(False)
+    # a CU-budgeted launch (atomics, fewer pixel splits)
+    d.cu_budget = 96
+    dwb = torch.zeros(cout, 9, cin, device=DEV)
+    ops.conv_wgrad(d, xs, gp, dwb)
+    torch.testing.assert_close(dwb.cpu(), ref, **tol)
+    # the 1x1 stride-2 shortcut's weight gradient reads phase (0, 0) of the same tensor
+    ws = torch.zeros(cout, cin, 1, 1, requires_grad=True)
+    (F.conv2d(xf.permute(0, 3, 1, 2), ws, stride=2) * gf.permute(0, 3, 1, 2)).sum().backward()
+    d1 = ops.conv_wgrad_desc_s2d(B, Hi, Wi, cin, cout, 1)
+    dw1 = torch.zeros(cout, 1, cin, device=DEV)
+    ops.conv_wgrad(d1, xs, gp, dw1)
+    r1 = ws.grad.view(cout, 1, cin)
+    torch.testing.assert_close(dw1.cpu(), r1, rtol=2e-3, atol=2e-3 * r1.abs().mean().item())

@@ -587,6 +587,11 @@ int nbdt_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float mom
  * per SIMD): every wave issues iters x 16 of them (x 32768 flop).  bench.py times the launch for `roofline.mfma_stream`
  * -- the power / clock ceiling of the matrix pipes on the box the bench runs on (csrc/probe.hip).  sink: >= 1 float. */
 int nbdt_probe_mfma_stream(int32_t blocks, int32_t iters, float* sink, void* stream);
+/* LDS-operand MFMA streams: the dense K loop's ds_read_b128 + MFMA mix with no LDS-DMA, barriers or epilogue, for the
+ * production tiling (variant 0: 8 waves x 64 pixels x 160 couts, 14 reads per 20 MFMAs) and for the one-wave-per-SIMD
+ * tiling (variant 1: 4 waves x 128 pixels x 160 couts, 18 reads per 40 MFMAs, software-pipelined).  160 MFMAs per CU and
+ * step either way: flops = blocks x iters x 160 x 32768.  Measurement only. */
+int nbdt_probe_lds_mfma(int32_t blocks, int32_t iters, int32_t variant, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,7 @@ int wgrad_taps_blocks(const nbdt_wgrad_desc* d);   // blocks of the 8-wave launc
 // wgrad_s2d.hip: 3x3 / stride-2 weight gradient over the space-to-depth copy of the input (ops.conv_wgrad_desc_s2d)
 bool wgrad_s2d_applicable(const nbdt_wgrad_desc* d);
 int wgrad_s2d(const nbdt_wgrad_desc* d, const void* x, const void* gy, float* dw, hipStream_t st);
+int wgrad_s2d_blocks(const nbdt_wgrad_desc* d);     // blocks (= CUs) of that launch, cu_budget applied
 
 // conv_dma.hip: LDS-DMA pipelined implicit GEMM (default path of nbdt_conv_igemm)
 struct BnBwdArgs {   // epilogue extras: the BatchNorm whose input gradient a dgrad launch produces (STATS mode 2)

@@ -43,6 +43,7 @@ extern "C" int nbdt_conv_wgrad_blocks(const nbdt_wgrad_desc* d) {
   if (!d || d->cin <= 0 || d->cin % 32 != 0 || d->cout <= 0 || d->cout % 32 != 0 || d->ntaps != 9) return 0;
   if (d->B <= 0 || d->gh <= 0 || d->gw <= 0) return 0;
   if (d->cu_budget != 0 && (d->cu_budget < 32 || d->cu_budget > 256)) return 0;
+  if (d->variant != 3 && nbdt::wgrad_s2d_applicable(d)) return nbdt::wgrad_s2d_blocks(d);
   return nbdt::wgrad_taps_blocks(d);
 }
 

@@ -401,11 +401,12 @@ bool wgrad_s2d_applicable(const nbdt_wgrad_desc* d) {
   return s2d_geometry(d, nullptr);
 }
 
-template <int WM>
-static int launch_s2d(WgradS2dParams& p, hipStream_t st) {
+// pixel split of a launch: one block per CU, whole rounds filled from below (d.cu_budget: the caller wants only that many
+// CUs filled -- an HBM-bound pass on another stream gets the rest), at least 16 stages per block
+static void s2d_split(WgradS2dParams& p, int wm) {
   const nbdt_wgrad_desc& d = p.d;
   p.n_ci_blocks = d.cin / 32;
-  const int tiles = (d.cout / (32 * WM)) * p.n_ci_blocks;
+  const int tiles = (d.cout / (32 * wm)) * p.n_ci_blocks;
   int cus = d.cu_budget > 0 ? d.cu_budget : 256;
   cus = std::max(8, std::min(cus, 256 - reserved_cus()));
   int splits = cus / tiles;
@@ -417,6 +418,20 @@ static int launch_s2d(WgradS2dParams& p, hipStream_t st) {
   p.splits = splits;
   p.items = tiles * splits;
   p.per_xcd = (p.items + 7) / 8;
+}
+
+int wgrad_s2d_blocks(const nbdt_wgrad_desc* d) {
+  WgradS2dParams p;
+  p.d = *d;
+  if (!s2d_geometry(d, &p)) return 0;
+  s2d_split(p, s2d_wm(d->cout));
+  return p.per_xcd * 8 < p.items ? p.per_xcd * 8 : p.items;
+}
+
+template <int WM>
+static int launch_s2d(WgradS2dParams& p, hipStream_t st) {
+  const nbdt_wgrad_desc& d = p.d;
+  s2d_split(p, WM);
   const size_t shmem = (size_t)4 * (64 * 64 * WM + (size_t)p.x_instr * 1024);
   const void* fn = reinterpret_cast<const void*>(&conv_wgrad_s2d_kernel<WM>);
   static DeviceAttr site;

@@ -83,6 +83,7 @@ SIGNATURES = {
     "nbdt_get_wgrad_store_epilogue": (c_int, []),
     "nbdt_set_reserved_cus": (c_int, [c_int32]),
     "nbdt_probe_mfma_stream": (c_int, [c_int32, c_int32, _P, _P]),
+    "nbdt_probe_lds_mfma": (c_int, [c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_get_reserved_cus": (c_int, []),
     "nbdt_tree_create": (c_int, [c_int, c_int, c_int, c_int, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P,
                                  POINTER(c_void_p)]),

@@ -194,16 +194,16 @@ class Conv:
     def forward_s2d(self, xs, out, Hi, Wi):
         ops.conv_igemm(self.s2d_plan(xs.shape[0], Hi, Wi)[0], xs, self._w_for(xs), out)
 
-    def backward_weight_s2d(self, xs, gout, Hi, Wi):
+    def backward_weight_s2d(self, xs, gout, Hi, Wi, cu_budget=0):
         desc = self.s2d_plan(xs.shape[0], Hi, Wi)[1]
         side = getattr(self, "side_stream", None)
         if side is None:
-            ops.conv_wgrad(desc, xs, gout, self.store.g(self.name))
+            ops.conv_wgrad(desc, xs, gout, self.store.g(self.name), cu_budget)
             return
         main = torch.cuda.current_stream(xs.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            ops.conv_wgrad(desc, xs, gout, self.store.g(self.name))
+            ops.conv_wgrad(desc, xs, gout, self.store.g(self.name), cu_budget)
 
     def backward_weight(self, x, gout, cu_budget=0):
         """cu_budget: CUs this launch is sized for when it runs on the second stream (0 = all of them): the caller
@@ -344,6 +344,8 @@ class _Engine:
         self._overlap = True
         self.use_seg = True       # shape-changing units on the slice-list kernel (conv_seg.hip); False: rounds 1-5's launches
         self._seg_ops = {}
+        self.seg_share = True     # ... with bn1's backward beside conv1's weight gradient on disjoint CUs (strided units; "all": every one; False: none)
+        self.seg_join = None      # wait for conv2's weight gradient before the slice-list data gradient: "small" (8x8 grids), "all", None
 
     def seg_op(self, key, build, sources, sources32, on_side=False):
         """The SegOp `key` (created, and its weights tiled, at first use: a new batch size or image size)."""
@@ -1083,14 +1085,35 @@ class WRNEngine(_Engine):
             if seg:
                 # conv1's and the shortcut's data gradients in one launch (strided: the four parity classes, the
                 # shortcut's gradient one more term of the even/even class); weight gradients read the same a1
-                if s == 2:
-                    u["conv1"].backward_weight_s2d(a1, gt, hi, wi)
-                    u["idconv"].backward_weight_s2d(a1, g, hi, wi)
+                x_in = u["x_in"]
+                if split and self.seg_share and (s == 2 or self.seg_share == "all"):
+                    # the CU-sharing order of the dense units: data gradient on the whole chip, then conv1's weight
+                    # gradient sized for 256 - n CUs beside bn1's backward on n (the unit's input gradient is bn1's alone:
+                    # conv1 and the shortcut both read relu(bn1(x)))
+                    if self.seg_join == "all" or (self.seg_join == "small" and ho * wo <= 64):
+                        # conv2's weight gradient outlasts the short BatchNorm pass it was paired with: the one-block-per-CU
+                        # data gradient that follows would find most CUs held and take as long as both
+                        self.join_side_stream()
+                    self._seg_dgrad(u, B, hi, wi)([gt, g], ga1)
+                    desc = u["conv1"].s2d_plan(B, hi, wi)[1] if s == 2 else u["conv1"].plan(B, hi, wi)[3]
+                    gbps, _, lo, hi_cus = self._cu_share
+                    budget, n1 = ops.plan_cu_share(desc, B * hi * wi * cin, self.share_bn2_tensors, gbps, self._share_split[1], lo, hi_cus)
+                    if s == 2:
+                        u["conv1"].backward_weight_s2d(a1, gt, hi, wi, cu_budget=budget)
+                        u["idconv"].backward_weight_s2d(a1, g, hi, wi)
+                    else:
+                        u["conv1"].backward_weight(a1, gt, cu_budget=budget)
+                        u["idconv"].backward_weight(a1, g)
+                    u["bn1"].backward_cus(ga1, x_in, g_in, n1)
                 else:
-                    u["conv1"].backward_weight(a1, gt)
-                    u["idconv"].backward_weight(a1, g)
-                self._seg_dgrad(u, B, hi, wi)([gt, g], ga1)
-                u["bn1"].backward(ga1, None, u["x_in"], g_in, relu=True)
+                    if s == 2:
+                        u["conv1"].backward_weight_s2d(a1, gt, hi, wi)
+                        u["idconv"].backward_weight_s2d(a1, g, hi, wi)
+                    else:
+                        u["conv1"].backward_weight(a1, gt)
+                        u["idconv"].backward_weight(a1, g)
+                    self._seg_dgrad(u, B, hi, wi)([gt, g], ga1)
+                    u["bn1"].backward(ga1, None, x_in, g_in, relu=True)
                 g, h, w = g_in, hi, wi
                 if comm is not None and u["key"] in ("s3u1", "s2u1"):
                     self.join_side_stream()

@@ -43,7 +43,8 @@ struct SegStep {          // one K step; 32 bytes, fetched with one s_load_dword
   int pf_pix;             // halo pixel of piece id0: id0 * 16
   int pf_choff;           // first channel of the slice being fetched
   int pf_tensor;          // input tensor of the slice being fetched
-  int strict;             // the pieces must be readable two steps later: the next step waits vmcnt(0)
+  int strict;             // bit 0: the pieces must be readable two steps later (the next step waits vmcnt(0));
+                          // bits 8..: waves that issue the step's last round
 };
 struct SegWStep { int matrix, w_off; };     // where a step's weight tile comes from (tiler, fp32 twin)
 struct SegRefStep { int tensor, ch0, dy, dx, matrix, w_off; };
@@ -62,6 +63,8 @@ struct ConvSegParams {
   const bf16_t* w_tiles;
   SegClassDev cls[4];
   int ncls, nbuf, tiles, tiles_per_xcd;
+  int overlap;            // the epilogue's LDS is laid out around halo buffer 0 and ring slot 0 [and 1: early_w1]
+  int early_w1;
 };
 
 }  // namespace nbdt
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     const bf16_t* src;      // tensor + channel of the slice being fetched
     int round_el;           // elements between rounds: 8 pieces x 16 pixels x pix_stride
     unsigned dst;           // LDS address of this wave's piece of round 0
+    int pix, ps;            // ragged tiles: halo pixel of piece id0, elements per pixel of the source tensor
   };
   auto load_step = [&](cint_ptr steps, int t) {
     nbdt::SegStep s;
@@ -259,15 +263,16 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
       q.ra[0][MW - 1] = smem3 + (r.abuf + o); q.ra[1][MW - 1] = smem3 + (r.abuf + (o ^ 32));
     }
     // rounds: pieces id0 + 8 j + wave; only the slice's last round can be short of waves
-    const int id0 = r.pf_pix >> 4;
-    int n = r.pf_n;
-    if (n > 0 && id0 + 8 * (n - 1) + wave >= a_instr) --n;
+    // (r.strict >> 8 = waves that issue the step's last round: the slice's last round can be short of waves)
+    const int n = r.pf_n - (wave >= (r.strict >> 8) ? 1 : 0);
     q.n = n;
-    q.strict = r.strict;
+    q.strict = r.strict & 1;
     const int ps = r.pf_tensor ? ps1 : ps0;
     q.src = (r.pf_tensor ? in1 : in0) + r.pf_choff;
     q.round_el = 128 * ps;
     q.dst = lds_base + r.pf_dst + wave * 1024;
+    q.pix = r.pf_pix;
+    q.ps = ps;
     const int px0 = lp + (base_pix_w + r.pf_pix);
     const int pxa = px0 < last_pix ? px0 : last_pix;
     int pxl = px0 + 128 * (n - 1);
@@ -297,7 +302,27 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     issue_w(t.w_tiles, 0, 0);
     if (t.nsteps > 1) issue_w(t.w_tiles, 1, 1);
   };
-  const EpiLds epi_lds = epi_lds_packed<NT, NWV>(smem, wave);
+  // ---- LDS of the epilogue (conv3x3_pp_kernel's scheme).  Packed from smem + 0 it overlaps halo buffer 0 and the ring, so
+  // the next tile cannot start before it is done.  With p.overlap (the launch checked that it fits) the per-wave regions
+  // go into halo buffers 1 .. nbuf-1 and behind ring slot 1 (or 0: !early_w1), and the next tile's slice 0 and W(0) [W(1)]
+  // are issued at the top of the epilogue: their round trip and the block's idle prologue disappear behind it.  A second
+  // prologue slice (classes that start with 1-tap slices) and a late W(1) follow after the epilogue.
+  constexpr int EPI_REGION = 32 * (2 * BN + 16);
+  EpiLds epi_lds = epi_lds_packed<NT, NWV>(smem, wave);
+  const bool overlap = p.overlap != 0, early_w1 = p.early_w1 != 0;
+  if (overlap) {
+    const int n_a = min(NWV, ((nbuf - 1) * a_bytes) / EPI_REGION);
+    unsigned char* tail = smem + nbuf * a_bytes + (early_w1 ? 2 : 1) * W_BYTES;
+    epi_lds.region = wave < n_a ? smem + a_bytes + wave * EPI_REGION : tail + (wave - n_a) * EPI_REGION;
+    epi_lds.row_off = (int*)(tail + (NWV - n_a) * EPI_REGION) + wave * 64;
+    epi_lds.blk_stats = (float*)(tail + (NWV - n_a) * EPI_REGION + NWV * 64 * 4);
+    epi_lds.base_a = smem + a_bytes; epi_lds.base_b = tail; epi_lds.n_a = n_a;
+  }
+  auto issue_early = [&](const Tile& t) {
+    issue_slice(t.pro_t0, t.pro_c0, t.base_pix, 0);
+    issue_w(t.w_tiles, 0, 0);
+    if (early_w1 && t.nsteps > 1) issue_w(t.w_tiles, 1, 1);
+  };
 
   issue_first(cur);
   for (;;) {   // ======================================= one (class, output tile) =======================================
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     li = cur.li;
     lane_constants();
     base_pix_w = cur.base_pix + wave * 16;
+    const bool ragged = cur.base_pix + (a_instr - 1) * 16 > last_pix;      // (more than the last piece reaches past the tensor)
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
@@ -365,7 +391,20 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
           ".Lseg_done_%=:"
           ::"s"(prev_a) : "memory", "scc");
       if (t + 2 < nsteps) issue_w(w_tiles, (K + 2) % 3, t + 2);
-      if (plan.n > 0) {
+      if (ragged) {
+        // a tile that reaches past the end of the tensor (fewer images than a tile holds): every piece clamps its own
+        // pixels (the fast path below lets only the slice's last piece overrun)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lp = ln >> 2, le = (((ln & 3) ^ ((ln >> 4) & 3)) << 3);
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j)
+          if (j < plan.n) {
+            int px = lp + (base_pix_w + plan.pix + 128 * j);
+            px = px < last_pix ? px : last_pix;
+            glds16_sf(plan.src, (unsigned)(px * plan.ps + le) * 2u, plan.dst + j * 8192);
+          }
+      } else if (plan.n > 0) {
         glds16_sf(plan.src, plan.voffL, plan.dst + (plan.n - 1) * 8192);
         const int m = plan.n - 1;       // rounds 0 .. m-1 share one lane offset; nested so that issuing is the fall-through path
 #define NBDT_ROUND(J) glds16_sf(plan.src + J * plan.round_el, plan.voff0, plan.dst + J * 8192)
@@ -423,7 +462,14 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
 #if NBDT_SEG_TIMING
     const unsigned tm_epi = seg_stamp();
 #endif
-    conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, pc, epi_lds, m0, n0, m_blk, wave, lane, tid);
+    const int next = li + nl;
+    const bool more = next < n_items;
+    const Tile nxt = more ? tile_of(next) : cur;
+    const bool early = more && overlap;
+    auto hook = [&]() {
+      if (early) issue_early(nxt);
+    };
+    conv_epilogue<NT, HAS_RES, STATS, NWV, MW>(acc, pc, epi_lds, m0, n0, m_blk, wave, lane, tid, nullptr, hook);
 #if NBDT_SEG_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
@@ -434,9 +480,18 @@ __global__ __launch_bounds__(512, 2) void conv_seg_kernel(nbdt::ConvSegParams p,
     }
 #endif
 
-    const int next = li + nl;
-    if (next >= n_items) break;
-    cur = tile_of(next);
+    if (!more) break;
+    cur = nxt;
+    if (early) {
+      const bool late_slice = cur.npro > 1, late_w1 = !early_w1 && cur.nsteps > 1;
+      if (late_slice || late_w1) {      // they land in LDS the epilogue used: every wave must be out of it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (late_slice) issue_slice(cur.pro_t1, cur.pro_c1, cur.base_pix, 1);
+        if (late_w1) issue_w(cur.w_tiles, 1, 1);
+      }
+      continue;
+    }
     // the packed epilogue LDS overlaps halo buffer 0 and the ring: every wave must be out of it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -669,6 +724,10 @@ static int seg_build(SegPlan* P, int tile, int nbuf) {
         const SegIssue& is = issue[t];
         r.pf_n = is.slice >= 0 ? is.n : 0;
         r.strict = is.slice >= 0 ? is.strict : 0;
+        {   // waves that issue the step's last round (pieces id0 + 8 (n - 1) + wave < a_instr), in bits 8..
+          const int last_waves = r.pf_n > 0 ? std::min(8, hg.a_instr - (is.round0 + r.pf_n - 1) * 8) : 8;
+          r.strict |= last_waves << 8;
+        }
         const int fs = is.slice >= 0 ? is.slice : 0;
         r.pf_dst = (fs % nbuf) * hg.a_bytes + is.round0 * 8 * 1024;
         r.pf_pix = is.round0 * 8 * 16;
@@ -708,9 +767,25 @@ static int seg_dev(SegPlan* P, SegPlan::Dev* out) {
 template <int NT, int MW>
 static int seg_launch(SegPlan* P, ConvSegParams& p, hipStream_t st) {
   constexpr int NWV = 8;
-  size_t shmem = (size_t)P->nbuf * P->hg.a_bytes + (size_t)3 * NT * 32 * BK * 2;
+  constexpr size_t W_BYTES = (size_t)NT * 32 * BK * 2;
+  constexpr size_t REGION = 32 * (2 * 32 * NT + 16), TABLES = NWV * 64 * 4 + 2 * 32 * NT * 4;
+  const size_t bufs = (size_t)P->nbuf * P->hg.a_bytes;
+  size_t shmem = bufs + 3 * W_BYTES;
   const size_t epi = conv_epilogue_lds_bytes<NT, NWV>();
   if (shmem < epi) shmem = epi;
+  // the epilogue's regions in halo buffers 1 .. nbuf-1 and behind ring slot 1 (W(0), W(1) early) or slot 0 (W(1) late)
+  p.overlap = 0; p.early_w1 = 0;
+  {
+    const size_t n_a = std::min<size_t>(NWV, ((size_t)(P->nbuf - 1) * P->hg.a_bytes) / REGION);
+    for (int early = 1; early >= 0 && !p.overlap; --early) {
+      const size_t need = bufs + (early ? 2 : 1) * W_BYTES + (NWV - n_a) * REGION + TABLES;
+      if (need <= 160 * 1024) {
+        p.overlap = 1; p.early_w1 = early;
+        if (shmem < need) shmem = need;
+      }
+    }
+    if (getenv("NBDT_SEG_NO_OVERLAP")) p.overlap = 0;       // (A/B)
+  }
   const int per_xcd_items = p.tiles_per_xcd * p.ncls;
   const int per_round = std::min(per_xcd_items, std::max(1, 32 - (reserved_cus() + 7) / 8));
   static DeviceAttr site;

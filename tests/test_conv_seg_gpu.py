@@ -285,3 +285,43 @@ def test_strided_weight_gradient_over_space_to_depth(B, Hi, Wi, cin, cout):
     ops.conv_wgrad(d1, xs, gp, dw1)
     r1 = ws.grad.view(cout, 1, cin)
     torch.testing.assert_close(dw1.cpu(), r1, rtol=2e-3, atol=2e-3 * r1.abs().mean().item())
+
+
+def _followed_by_nan(t):
+    """The same tensor placed so that the memory right behind it is NaN: a tile that reaches past the end of a tensor (fewer
+    images than a tile holds) must clamp every LDS-DMA piece -- what it loads for its dead pixels never reaches the output,
+    but it reaches the accumulators, and NaN x 0 in the fused statistics is NaN."""
+    n = t.numel()
+    buf = torch.full((n + (1 << 20),), float("nan"), dtype=t.dtype, device=t.device)
+    buf[:n] = t.reshape(-1)
+    return buf[:n].view(t.shape)
+
+
+@pytest.mark.parametrize("B,Hi,Wi,cin,cout,tile", [(5, 8, 8, 96, 160, 256), (3, 16, 16, 64, 64, 512), (9, 16, 16, 32, 160, 256)])
+def test_ragged_tiles_never_read_past_the_tensors(B, Hi, Wi, cin, cout, tile):
+    xf, xp = _rand_act(B, Hi, Wi, cin, seed=1)
+    w_oihw, wb = _rand_weight(cout, cin, 3, seed=2)
+    Ho, Wo = Hi // 2, Wi // 2
+    try:
+        plan = ops.seg_fwd_s2(B, Hi, Wi, cin, cout, tile=tile)
+    except Exception:
+        pytest.skip("shape does not fit the forced tile")
+    xs = _followed_by_nan(_s2d(xp, B, Hi, Wi, cin))
+    wt = plan.tile_weights([wb])
+    out = ops.padded(B, Ho, Wo, cout, DEV)
+    M = B * Ho * Wo
+    scr = torch.zeros(((M + 255) // 256) * 2 * cout, device=DEV)
+    plan([xs], wt, out, bn_scratch=scr)
+    assert not torch.isnan(scr).any() and not torch.isnan(out.float()).any()
+    o = ops.interior(out).float().cpu().reshape(-1, cout)
+    torch.testing.assert_close(scr.view(-1, 2, cout).sum(0)[0].cpu(), o.sum(0), rtol=1e-3, atol=1e-2)
+    # the data-gradient classes over a gradient tensor followed by NaN
+    gf, gp = _rand_act(B, Ho, Wo, cout, seed=4)
+    wd = wb.flip(1).permute(2, 1, 0).contiguous()
+    dplan = ops.seg_dgrad_s2(B, Hi, Wi, cin, cout, tile=tile)
+    dwt = dplan.tile_weights([wd])
+    gx = ops.padded(B, Hi, Wi, cin, DEV)
+    dplan([_followed_by_nan(gp)], dwt, gx)
+    x = torch.zeros(B, cin, Hi, Wi, requires_grad=True)
+    (F.conv2d(x, w_oihw, stride=2, padding=1) * gf.permute(0, 3, 1, 2)).sum().backward()
+    _close_bf16(ops.interior(gx), x.grad.permute(0, 2, 3, 1), "strided data gradient (ragged)")

@@ -45,7 +45,7 @@ PEAK_BF16_TFLOPS = 2500.0
 GFLOP_PER_IMG_TRAIN = 31.46     # WRN-28-10 @32x32: fwd 10.487 GFLOP (2*MAC) x3
 
 
-TRAFFIC_FILES = ("r05_final_hbm_traffic.json", "r04_final_hbm_traffic.json", "r03_split_hbm_traffic.json", "r02_final_hbm_traffic.json")   # newest first
+TRAFFIC_FILES = ("r06_final_hbm_traffic.json", "r05_final_hbm_traffic.json", "r04_final_hbm_traffic.json")   # newest first
 LOGIT_TOLERANCE = 3e-2          # max |logit error| / logit scale against the fp32 CPU port
 
 
@@ -56,8 +56,10 @@ def pmc_traffic(launches_per_step):
     same command with --no-overlap; scratch/prof_bench.sh + scratch/traffic_report.py).  bench.py cannot collect PMC counters itself, so the
     number is only quoted when the file was recorded from THE SAME LAUNCHES: its "_meta" entry lists the implicit-GEMM
     kernels' launches per step by device kernel name, and `launches_per_step` is what this run's roofline pass
-    counted (nbdt_debug_last_igemm after every launch).  Any difference -- a kernel renamed, added, re-routed --
-    gives (None, reason) instead of a stale number."""
+    counted (nbdt_debug_last_igemm_full after every launch: the device kernel WITH its template arguments, as rocprofv3
+    prints it -- round 5's guard compared family names and let a file recorded before a template parameter was added
+    through).  Any difference -- a kernel renamed, re-instantiated, added, re-routed -- gives (None, reason) instead of a
+    stale number."""
     for fname in TRAFFIC_FILES:
         path = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(path):
@@ -76,7 +78,7 @@ def pmc_traffic(launches_per_step):
                       "not quoted")
     n = b = 0
     for name, v in t.items():
-        if "conv3x3_pp_kernel" in name or "conv3x3_halo_kernel" in name or "conv_igemm_dma" in name:
+        if "conv3x3_pp_kernel" in name or "conv3x3_halo_kernel" in name or "conv_igemm_dma" in name or "conv_seg_kernel" in name:
             n += v["launches"]
             b += v["launches"] * (v["fetch_bytes_x2"] + v["write_bytes"])
     return (round(b / n) if n else None), "profiles/" + fname
@@ -399,9 +401,26 @@ def main():
         # roofline pass puts every launch back on one stream (this costs ~3 % of step time, not counted anywhere).
         eng.set_overlap(False)
         ops.set_timer(timer)
-        for _ in range(roof_steps):
-            E.train_step(eng, crit, img, y, lr, comm=comm)
-        sync()
+        # ... and the rules layer: HIP events around the fused head launch (classifier + rules + SoftTreeSupLoss
+        # forward and backward, nbdt_head_soft_tree_loss) of the same steps
+        head_events = []
+        real_head = crit.head_loss_and_grad
+
+        def timed_head(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = real_head(*a, **k)
+            e1.record()
+            head_events.append((e0, e1))
+            return r
+
+        crit.head_loss_and_grad = timed_head
+        try:
+            for _ in range(roof_steps):
+                E.train_step(eng, crit, img, y, lr, comm=comm)
+            sync()
+        finally:
+            crit.head_loss_and_grad = real_head
         ops.set_timer(None)
         eng.set_overlap(not args.no_overlap)
 
@@ -464,15 +483,18 @@ def main():
                        "ms_per_step_without_allreduce": round(1e3 * dt_nocomm, 3),
                        "allreduce_ms_exposed": round(ms - 1e3 * dt_nocomm, 3)}
         out["comm"].update(comm.describe(int(eng.store.grad.numel()) * 4))
+        out["comm"]["grad_buckets_planned"] = [list(r) for r in eng.grad_buckets()]      # [stage 3 .. head], [stage 2], [stem .. stage 1]
     if timer is not None:
         summ = timer.summary()
         traffic, traffic_src = pmc_traffic({k: v / roof_steps for k, v in timer.kernels.items()})
         k = summ.get("conv_igemm")
         if k:
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "conv_igemm: conv3x3_pp_kernel (44 launches, 96 % of the flops) / "
-                                         "conv_igemm_dma[_multi]_kernel (strided, 1x1, parity-class launches) -- every "
-                                         "forward + data-gradient implicit GEMM, 2/3 of the step's flops",
+                               "kernel": "conv_igemm: conv3x3_pp_kernel (41 dense 3x3 launches) / conv_seg_kernel (the "
+                                         "shape-changing units: strided conv1 over the space-to-depth input, conv2 + "
+                                         "shortcut in one launch, conv1 + shortcut data gradients in one launch; 8 launches) "
+                                         "/ conv_igemm_dma_kernel (one 1x1) -- every forward + data-gradient implicit GEMM, "
+                                         "2/3 of the step's flops",
                                "achieved": round(k["tflops"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "traffic_source": traffic_src,
@@ -496,8 +518,8 @@ def main():
         w = summ.get("conv_wgrad")
         if w:
             out["roofline_wgrad"] = {"bound": "mfma",
-                                     "kernel": "conv_wgrad: conv_wgrad_ks_kernel (22 of 27 launches) / "
-                                               "conv_wgrad_dma_kernel (strided, 1x1, 16-channel input)",
+                                     "kernel": "conv_wgrad: conv_wgrad_ks_kernel (23 of 28 launches) / conv_wgrad_s2d_kernel "
+                                               "(the two strided 3x3) / conv_wgrad_dma_kernel (the three 1x1 shortcuts)",
                                      "achieved": round(w["tflops"], 1),
                                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(w["tflops"] / PEAK_BF16_TFLOPS, 4),
@@ -513,6 +535,27 @@ def main():
                                         f"{roof_steps} further steps of the timed schedule (CU-budgeted launches beside "
                                         "the CU-confined BatchNorm passes; fraction of the FULL chip's peak)"})
             out["step_ms_in_mfma_kernels"] = round((k["ms"] + w["ms"]) / roof_steps, 3) if k else None
+        if head_events:
+            # Rules layer computed from features (north star): algorithmic bytes 4 (B F + R F + B C) and flops
+            # 2 B R F with R = child slots of the hierarchy -- the survey's formula (the backward half's dL/dpooled write and
+            # classifier-gradient atomics are of the same order and not counted).  The honest bound is one kernel boundary.
+            us = 1e3 * sum(a.elapsed_time(b) for a, b in head_events) / len(head_events)
+            Bh, F_, C_ = args.batch, eng.feat_c, args.classes
+            R_ = int(crit.tree.flat().num_slots) if hasattr(crit.tree, "flat") else 2 * (C_ - 1)
+            nbytes = 4 * (Bh * F_ + R_ * F_ + Bh * C_)
+            out["roofline_rules"] = {"bound": "hbm", "kernel": "head_soft_loss_kernel (nbdt_head_soft_tree_loss): classifier "
+                                     "forward + node logits + per-node softmax / path products + SoftTreeSupLoss + the "
+                                     "classifier's backward, one launch; the logits never reach HBM",
+                                     "us_per_step": round(us, 1), "algorithmic_bytes": nbytes,
+                                     "achieved": round(nbytes / (us * 1e-6) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(nbytes / (us * 1e-6) / 8e12, 6),
+                                     "flops": 2 * Bh * R_ * F_, "child_slots": R_,
+                                     "stated_bound": "one kernel boundary (~1.5 us): 1.3 MB at 8 TB/s is 0.17 us -- the launch is "
+                                                     "latency-bound (512 samples x 18 child slots; 4 samples per block), not "
+                                                     "bandwidth-bound",
+                                     "share_of_step": round(us * 1e-3 / ms, 5),
+                                     "measured": f"HIP events around the launch in {roof_steps} steps continuing the timed loop "
+                                                 "(one stream)"}
     if world == 1 and args.agreement_n > 0:
         out["agreement"] = agreement(eng, args.classes, args.agreement_n, dev)
     if world == 1 and not args.no_other_configs:

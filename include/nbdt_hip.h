@@ -48,6 +48,9 @@ const char* nbdt_last_error(void);
 /* Name of the device kernel the calling thread's last nbdt_conv_igemm* call launched ("conv3x3_pp_kernel",
  * "conv3x3_halo_kernel", "conv_igemm_dma_kernel"): lets the parity tests assert WHICH kernel they exercised. */
 const char* nbdt_debug_last_igemm(void);
+/* the same with the kernel's template arguments, spelled as rocprofv3 prints it ("conv3x3_pp_kernel<5, false, 0, 8, false,
+ * 2>"): what bench.py compares with the kernel names of a committed PMC traffic file before quoting it */
+const char* nbdt_debug_last_igemm_full(void);
 const char* nbdt_debug_last_wgrad(void);      /* same for nbdt_conv_wgrad */
 int nbdt_version(void);
 /* Deterministic mode (process-wide switch, default off).  The reference's CPU path (stock ATen ops,

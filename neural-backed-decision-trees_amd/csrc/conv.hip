@@ -66,6 +66,7 @@ static int check_desc(const nbdt_conv_desc* d) {
 }
 
 extern "C" const char* nbdt_debug_last_igemm(void) { return nbdt::g_last_igemm; }
+extern "C" const char* nbdt_debug_last_igemm_full(void) { return nbdt::g_last_igemm_full; }
 
 extern "C" int nbdt_conv_igemm_multi(const nbdt_conv_desc* descs, int32_t n, const void* in, const void* w, void* out,
                                      void* stream) {

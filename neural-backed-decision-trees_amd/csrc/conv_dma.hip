@@ -215,7 +215,11 @@ static int launch_dma(ConvDmaParams& p, hipStream_t st) {
     site.done(shmem);
   }
   const dim3 grid(p.per_xcd * 8), blk(256);
-#define NBDT_GO(R, S) hipLaunchKernelGGL((conv_igemm_dma_kernel<NT, R, S>), grid, blk, shmem, st, p)
+#define NBDT_GO(R, S)                                                                                              \
+  do {                                                                                                                \
+    snprintf(g_last_igemm_full, sizeof(g_last_igemm_full), "conv_igemm_dma_kernel<%d, %s, %d>", NT, R ? "true" : "false", S); \
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<NT, R, S>), grid, blk, shmem, st, p);                                \
+  } while (0)
   if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
   else if (p.bn_x != nullptr) NBDT_GO(false, 2);
   else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
@@ -249,6 +253,7 @@ static int launch_dma_multi(ConvDmaMulti& mp, int n, bool accumulate, hipStream_
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     site.done(shmem);
   }
+  snprintf(g_last_igemm_full, sizeof(g_last_igemm_full), "conv_igemm_dma_multi_kernel<%d, %s>", NT, accumulate ? "true" : "false");
   if (accumulate) hipLaunchKernelGGL((conv_igemm_dma_multi_kernel<NT, true>), dim3(blocks), dim3(256), shmem, st, mp);
   else hipLaunchKernelGGL((conv_igemm_dma_multi_kernel<NT, false>), dim3(blocks), dim3(256), shmem, st, mp);
   NBDT_LAUNCH_CHECK();

@@ -832,6 +832,7 @@ int conv_ksplit_rule(const nbdt_conv_desc& d, int nt, int items) {
 }
 
 thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): which kernel the last launch used
+thread_local char g_last_igemm_full[128] = "";
 
 // KIND 0: conv3x3_pp_kernel<.., 8> (ping-pong), 1: conv3x3_pp_kernel<.., 4> (same segments, one group, two blocks
 // per CU), 2: conv3x3_halo_kernel (4 waves, plain weight layout), 3: conv3x3_pp_kernel<.., 8, false, 1> (ping-pong,
@@ -903,7 +904,13 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
     site.done(shmem);
   }
   void* args[] = {(void*)&p, (void*)&hg};
-#define NBDT_GO(R, S) NBDT_HIP_CHECK(hipLaunchKernel(NBDT_KERNEL(R, S), grid, blk, args, shmem, st))
+#define NBDT_GO(R, S)                                                                                               \
+  do {                                                                                                                 \
+    if (KIND == 2) snprintf(g_last_igemm_full, sizeof(g_last_igemm_full), "conv3x3_halo_kernel<%d, %s, %d>", NT, R ? "true" : "false", S); \
+    else snprintf(g_last_igemm_full, sizeof(g_last_igemm_full), "conv3x3_pp_kernel<%d, %s, %d, %d, %s, %d>", NT,     \
+                  R ? "true" : "false", S, NWV, PAD ? "true" : "false", MW);                                        \
+    NBDT_HIP_CHECK(hipLaunchKernel(NBDT_KERNEL(R, S), grid, blk, args, shmem, st));                                 \
+  } while (0)
   if (p.aff_scale != nullptr) { if (p.res != nullptr) NBDT_GO(true, 3); else NBDT_GO(false, 3); }
   else if (p.bn_x != nullptr) NBDT_GO(false, 2);
   else if (p.res != nullptr) { if (p.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }

@@ -799,7 +799,11 @@ static int seg_launch(SegPlan* P, ConvSegParams& p, hipStream_t st) {
   }
   const dim3 grid(per_round * 8), blk(64 * NWV);
   void* args[] = {(void*)&p, (void*)&P->hg};
-#define NBDT_GO(R, S) NBDT_HIP_CHECK(hipLaunchKernel(NBDT_KERNEL(R, S), grid, blk, args, shmem, st))
+#define NBDT_GO(R, S)                                                                                                \
+  do {                                                                                                                  \
+    snprintf(g_last_igemm_full, sizeof(g_last_igemm_full), "conv_seg_kernel<%d, %s, %d, %d>", NT, R ? "true" : "false", S, MW); \
+    NBDT_HIP_CHECK(hipLaunchKernel(NBDT_KERNEL(R, S), grid, blk, args, shmem, st));                                  \
+  } while (0)
   if (p.c.res != nullptr) { if (p.c.stats) NBDT_GO(true, 1); else NBDT_GO(true, 0); }
   else { if (p.c.stats) NBDT_GO(false, 1); else NBDT_GO(false, 0); }
 #undef NBDT_GO

@@ -90,6 +90,7 @@ SIGNATURES = {
     "nbdt_tree_destroy": (c_int, [c_void_p]),
     "nbdt_tree_max_depth": (c_int, [c_void_p]),
     "nbdt_debug_last_igemm": (c_char_p, []),
+    "nbdt_debug_last_igemm_full": (c_char_p, []),
     "nbdt_debug_last_wgrad": (c_char_p, []),
     "nbdt_conv_wgrad_blocks": (c_int, [_P]),
     "nbdt_conv_plan": (c_int, [_P, _P, _P]),

@@ -120,13 +120,17 @@ class GradComm:
         self.force = bool(force) and dist.is_initialized()
         self._stream = None
         self._work = []
+        self.last_ranges = []     # (lo, hi) element ranges of the buckets issued since the last finish(), in issue order
+        self._issued = []
         # CUs the collective's kernels occupy while a bucket is in flight (one block per channel); 0 for gloo / 1 rank
         rccl = dist.is_initialized() and dist.get_backend(group) == "nccl" and (self.world_size > 1 or self.force)
         self.reserved_cus = reserved_cus_for_rccl() if rccl else 0
 
     def describe(self, nbytes):
         """What bench.py puts into its `comm` object about the exchange of `nbytes` per rank."""
-        return {"rccl_max_nchannels": rccl_channels(), "rccl_channels_set_by": RCCL["set_by"],
+        return {"bucket_ranges_last_step": [list(r) for r in self.last_ranges],
+                "bucket_bytes_last_step": [4 * (hi - lo) for lo, hi in self.last_ranges],
+                "rccl_max_nchannels": rccl_channels(), "rccl_channels_set_by": RCCL["set_by"],
                 "reserved_cus_while_buckets_in_flight": self.reserved_cus,
                 "allreduce_model_ms": round(allreduce_model_ms(nbytes, self.world_size), 3),
                 "allreduce_model": f"ring, 2(N-1)/N x {nbytes} B per rank over {rccl_channels() or DEFAULT_RCCL_CHANNELS} "
@@ -137,6 +141,7 @@ class GradComm:
         that wrote this range is ordered before it."""
         if (self.world_size == 1 and not self.force) or hi <= lo:
             return
+        self._issued.append((int(lo), int(hi)))
         view = flat[lo:hi]
         if flat.is_cuda:
             if self._stream is None:
@@ -162,6 +167,7 @@ class GradComm:
         for w in self._work:
             w.wait()
         self._work = []
+        self.last_ranges, self._issued = self._issued, []
         if self._stream is not None and flat is not None and flat.is_cuda:
             torch.cuda.current_stream(flat.device).wait_stream(self._stream)
 

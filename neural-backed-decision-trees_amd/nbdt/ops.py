@@ -275,7 +275,7 @@ def conv_igemm(desc, inp, w_bf16, out, residual=None, bn_scratch=None):
                                           ptr(bn_scratch), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
-        _timer.count(last_igemm_kernel())
+        _timer.count(last_igemm_kernel_full())
 
 
 def desc_flops(desc):
@@ -301,7 +301,7 @@ def conv_igemm_multi(descs, inp, w_bf16, out):
     check(lib().nbdt_conv_igemm_multi(arr, len(descs), ptr(inp), ptr(w_bf16), ptr(out), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
-        _timer.count(last_igemm_kernel())
+        _timer.count(last_igemm_kernel_full())
 
 
 def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, partials):
@@ -316,7 +316,7 @@ def conv_igemm_bnbwd(desc, inp, w_bf16, out, bn_x, mean, rstd, gamma, beta, part
                                       ptr(rstd), ptr(gamma), ptr(beta), ptr(partials), stream_ptr(inp.device)))
     if ev is not None:
         ev[1].record()
-        _timer.count(last_igemm_kernel())
+        _timer.count(last_igemm_kernel_full())
 
 
 def conv_igemm_affine(desc, inp, w_bf16, out, scale, shift, act=1, residual=None):
@@ -450,6 +450,11 @@ def weight_tiles(w_bf16):
 def last_igemm_kernel():
     """Name of the device kernel this thread's last conv_igemm* call launched (tests assert on it)."""
     return lib().nbdt_debug_last_igemm().decode()
+
+
+def last_igemm_kernel_full():
+    """... with its template arguments, as rocprofv3 prints the device kernel (bench.py's traffic guard)."""
+    return lib().nbdt_debug_last_igemm_full().decode()
 
 
 def last_wgrad_kernel():
@@ -778,7 +783,7 @@ class ConvSeg:
         check(lib().nbdt_conv_seg(self.handle, arr, ptr(w), ptr(out), ptr(residual), ptr(bn_scratch), stream_ptr(dev)))
         if ev is not None:
             ev[1].record()
-            _timer.count(last_igemm_kernel())
+            _timer.count(last_igemm_kernel_full())
 
     def __del__(self):
         try:

@@ -31,12 +31,13 @@ if os.environ.get("SMALL", "1") == "1":
             if c < 0.98: print(f"   {name}: cos {c:.4f} norms {a.norm():.4g} {b.norm():.4g}")
 B = int(os.environ.get("B", 512))
 img = torch.randn(B, 3, 32, 32, generator=g).cuda(); y = torch.randint(0, 10, (B,), generator=g).cuda()
-cfgs = [(False, False, None), (True, False, None), (True, True, None), (True, True, "small"), (True, True, "all"), (True, "all", "small")]
-for seg, share, join in cfgs + cfgs:
+cfgs = [(False, False, None), (True, False, None), (True, True, None)]
+for seg, share, join in cfgs + cfgs + cfgs:
     eng = engine.WRNEngine(num_classes=10, blocks=28, width_factor=10, device="cuda:0", seed=0)
     eng.use_seg = seg
     eng.seg_share = share
     eng.seg_join = join
+    eng.set_cu_share(47.0, calibrate=False)
     for _ in range(4): engine.train_step(eng, crit, img, y, lr=0.01)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): engine.train_step(eng, crit, img, y, lr=0.01)

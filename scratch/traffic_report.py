@@ -37,11 +37,10 @@ with open(prefix + "_hbm_traffic.txt", "w") as fo:
 if steps:
     per_step = collections.defaultdict(float)
     for k, v in out.items():
-        fam = re.sub(r"<.*", "", k.replace("void ", ""))
-        if fam in ("conv3x3_pp_kernel", "conv3x3_halo_kernel", "conv_igemm_dma_kernel", "conv_igemm_dma_multi_kernel"):
-            if fam == "conv3x3_pp_kernel" and re.search(r", 4>$", k):
-                fam = "conv3x3_pp_kernel/4w"          # the name nbdt_debug_last_igemm reports for the 4-wave form
-            per_step[fam] += v["launches"] / steps
+        name = k.replace("void ", "")
+        fam = re.sub(r"<.*", "", name)
+        if fam in ("conv3x3_pp_kernel", "conv3x3_halo_kernel", "conv_igemm_dma_kernel", "conv_igemm_dma_multi_kernel", "conv_seg_kernel"):
+            per_step[name] += v["launches"] / steps          # full device kernel name, template arguments included
     out["_meta"] = {"steps_profiled": steps, "igemm_launches_per_step": dict(per_step)}
 with open(prefix + "_hbm_traffic.json", "w") as fo:
     json.dump(out, fo, indent=1)

@@ -33,6 +33,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["attainable_kernel"] == "conv3x3_pp_kernel" and 0 < r["attainable"] <= r["mfma_stream"] * 1.02 < 1.02 * r["peak"]
     assert abs(r["frac_of_attainable"] - r["achieved"] / r["attainable"]) < 1e-3
     assert 0.3 < r["attainable_frac_of_peak"] < 1 and 0.5 < r["mfma_stream_frac_of_peak"] < 1
+    # the rules layer's own roofline object: wall us of the fused head launch, its algorithmic bytes, GB/s
+    rr = d["roofline_rules"]
+    assert rr["bound"] == "hbm" and rr["unit"] == "GB/s" and rr["peak"] == 8000.0 and rr["us_per_step"] > 0
+    assert rr["algorithmic_bytes"] == 4 * (64 * 640 + rr["child_slots"] * 640 + 64 * 10) and rr["child_slots"] == 18
+    assert abs(rr["achieved"] - rr["algorithmic_bytes"] / (rr["us_per_step"] * 1e-6) / 1e9) < 0.02 * rr["achieved"] + 0.01
+    assert "one kernel boundary" in rr["stated_bound"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
@@ -101,4 +107,13 @@ def test_bench_n_rank_branch_at_the_driver_rank_counts(ranks):
     assert len(c["cu_share_per_rank"]) == ranks and len(set(c["cu_share_per_rank"])) == 1      # rank 0 decided for all
     assert len(c["replica_checksums"]) == ranks and c["replicas_identical"], c["replica_checksums"]
     assert c["replica_checksums"][0][1] > 0
+    # the exchange the first real 8-GPU run will make, asserted rather than assumed -- the three
+    # buckets are issued in the order backward completes them (stage 3 + head first: the highest offsets of the flat
+    # buffer), they tile the whole gradient buffer exactly once, and the CU reservation follows the backend
+    rng = c["bucket_ranges_last_step"]
+    assert rng == c["grad_buckets_planned"] and len(rng) == 3
+    assert rng[0][0] > rng[1][0] > rng[2][0] == 0 and rng[0][1] * 4 == c["allreduce_bytes_per_rank"]
+    assert rng[1][1] == rng[0][0] and rng[2][1] == rng[1][0]
+    assert sum(c["bucket_bytes_last_step"]) == c["allreduce_bytes_per_rank"]
+    assert c["reserved_cus_while_buckets_in_flight"] == (c["rccl_max_nchannels"] if multi else 0)
     assert abs(d["value"] - 64 * ranks * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]

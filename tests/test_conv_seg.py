@@ -60,7 +60,9 @@ def check_schedule(plan, gh, gw):
             lo = last[si - plan.nbuf] + 1 if si >= plan.nbuf else 0
             hi = first[si] - 2
             assert lo <= tt <= hi, (c, tt, si, lo, hi)
-            assert int(r[7]) == (1 if tt == hi else 0)
+            assert int(r[7]) & 1 == (1 if tt == hi else 0)
+            # bits 8..: how many waves issue the step's last round (the slice's last round can be short of waves)
+            assert int(r[7]) >> 8 == min(8, a_instr - (id0 + 8 * (n - 1)))
             got[si].extend(range(id0 // 8, id0 // 8 + n))
         for si in range(len(slices)):
             if si < npro:

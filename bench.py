@@ -541,7 +541,7 @@ def main():
             # classifier-gradient atomics are of the same order and not counted).  The honest bound is one kernel boundary.
             us = 1e3 * sum(a.elapsed_time(b) for a, b in head_events) / len(head_events)
             Bh, F_, C_ = args.batch, eng.feat_c, args.classes
-            R_ = int(crit.tree.flat().num_slots) if hasattr(crit.tree, "flat") else 2 * (C_ - 1)
+            R_ = int(crit.tree.flat.num_slots)
             nbytes = 4 * (Bh * F_ + R_ * F_ + Bh * C_)
             out["roofline_rules"] = {"bound": "hbm", "kernel": "head_soft_loss_kernel (nbdt_head_soft_tree_loss): classifier "
                                      "forward + node logits + per-node softmax / path products + SoftTreeSupLoss + the "

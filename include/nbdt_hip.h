@@ -200,7 +200,9 @@ typedef struct nbdt_conv_desc {
                                    256-pixel kernel, 4 = force 512-pixel tiles with the padded LDS pitch (images narrower
                                    than 32 pixels: bank-conflict-free halo reads, measured 1-2 % slower, so never picked
                                    automatically), 5 = force half tiles.  2 - 5 exist for tests and A/B measurements. */
-  int32_t ksplit;               /* half tiles on at most half the CUs: blocks per output tile, each a range of the 32-channel
+  int32_t ksplit;               /* (a reserved, ignored field before nbdt_version() 106: zero-initialise descriptors;
+                                   negative values, and n > 1 without wide_tile = 5, are NBDT_EINVAL)
+                                   half tiles on at most half the CUs: blocks per output tile, each a range of the 32-channel
                                    input slices (partials through a per-stream fp32 workspace, the last block sums them in
                                    split order and runs the epilogue).  0 = automatic (only with an automatic wide_tile),
                                    1 = never, n = n blocks per tile (tests, A/B; with wide_tile = 5) */

@@ -210,6 +210,7 @@ struct HaloGeom {
 };
 bool conv_halo_applicable(const nbdt_conv_desc* d, int M, HaloGeom* hg);
 int conv_ksplit_rule(const nbdt_conv_desc& d, int nt, int items);      // blocks per half tile the launch rule asks for
+int conv_halo_items(const nbdt_conv_desc& d, const HaloGeom& hg, int M, int* nt_out);   // (cout tile, items) of a launch
 extern thread_local const char* g_last_wgrad;   // ... and the last nbdt_conv_wgrad call
 extern thread_local const char* g_last_igemm;   // name of the kernel the last nbdt_conv_igemm* call launched (tests)
 extern thread_local char g_last_igemm_full[128];  // ... with its template arguments, as a profiler prints it (bench.py's traffic guard)

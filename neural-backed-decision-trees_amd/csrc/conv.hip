@@ -62,6 +62,9 @@ static int check_desc(const nbdt_conv_desc* d) {
                "output pixel offsets must be 8-byte aligned");
   for (int t = 0; t < d->ntaps; ++t) NBDT_REQUIRE(d->tap_off[t] % 8 == 0, "tap offsets must be 16-byte aligned");
   NBDT_REQUIRE((int64_t)d->B * d->gh * d->gw < (1ll << 31), "pixel grid too large");
+  // (ksplit was a reserved, ignored field before version 106: descriptors must be zero-initialised)
+  NBDT_REQUIRE(d->ksplit >= 0, "ksplit: 0 (automatic), 1 (never) or n blocks per tile");
+  NBDT_REQUIRE(d->ksplit <= 1 || d->wide_tile == 5, "ksplit > 1 goes with wide_tile = 5 (forced half tiles; tests, A/B)");
   return NBDT_OK;
 }
 
@@ -99,9 +102,8 @@ extern "C" int nbdt_conv_plan(const nbdt_conv_desc* d, int32_t* form, int32_t* k
   }
   if (hg.nwv != 8) { *form = 1; return NBDT_OK; }
   if (hg.mw == 1) {
-    const int nt32 = d->cout / 32;
-    const int nt = nt32 % 5 == 0 ? 5 : (nt32 % 4 == 0 ? 4 : (nt32 % 2 == 0 ? 2 : 1));
-    const int items = (int)((M64 + 255) / 256) * (d->cout / (32 * nt));
+    int nt = 0;
+    const int items = nbdt::conv_halo_items(*d, hg, (int)M64, &nt);     // the launcher's own arithmetic
     *form = 4;
     *ksplit = nbdt::conv_ksplit_rule(*d, nt, items);
     return NBDT_OK;

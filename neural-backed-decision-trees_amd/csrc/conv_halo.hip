@@ -555,7 +555,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
     __syncthreads();                                    // read before the next tile's first DMA may land there
     run_epilogue = ticket == (unsigned)(ksplit - 1);
     if (run_epilogue) {
-      if (tid == 0) p.k_tickets[cur.tile] = 0;          // ready for the next launch
+      // ready for the next launch: an agent-scope atomic like the increments (a plain store beside sc1 atomics in the
+      // same line relied on the end-of-kernel write-back for the next launch to see the zero -- ADVICE r5)
+      if (tid == 0) __hip_atomic_store(p.k_tickets + cur.tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (agent-scope relaxed loads, 8 bytes each: the compiler keeps a whole split's worth in flight)
       const unsigned long long* all = (const unsigned long long*)((const f32x4*)p.k_ws + (size_t)cur.tile * ksplit * NQ * (64 * NWV) + tid);
 #pragma unroll
@@ -831,6 +833,19 @@ int conv_ksplit_rule(const nbdt_conv_desc& d, int nt, int items) {
   return S < 1 ? 1 : S;
 }
 
+static int cout_tile(int cout) {
+  const int nt32 = cout / 32;
+  return nt32 % 5 == 0 ? 5 : (nt32 % 4 == 0 ? 4 : (nt32 % 2 == 0 ? 2 : 1));
+}
+
+// (cout tile, items) of a launch with this tile geometry: the ONE place the launcher and nbdt_conv_plan take them from
+int conv_halo_items(const nbdt_conv_desc& d, const HaloGeom& hg, int M, int* nt_out) {
+  const int nt = cout_tile(d.cout);
+  const int bmh = 32 * hg.mw * hg.nwv;
+  if (nt_out) *nt_out = nt;
+  return ((M + bmh - 1) / bmh) * (d.cout / (32 * nt));
+}
+
 thread_local const char* g_last_igemm = "";     // nbdt_debug_last_igemm(): which kernel the last launch used
 thread_local char g_last_igemm_full[128] = "";
 
@@ -845,7 +860,8 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   constexpr int BMH = 32 * MW * NWV;
   p.n_blocks = p.d.cout / BN;
   p.m_blocks = (p.M + BMH - 1) / BMH;
-  int items = p.m_blocks * p.n_blocks;
+  int items = conv_halo_items(p.d, hg, p.M, nullptr);      // (= m_blocks * n_blocks for this instantiation's NT, MW, NWV)
+  if (items != p.m_blocks * p.n_blocks) return nbdt::fail(NBDT_EINVAL, "%s%s", "conv_halo_items disagrees with the launcher", "");
   p.ksplit = 1; p.k_ws = nullptr; p.k_tickets = nullptr;
   if (KIND == 3) {
     // Half tiles on at most half the CUs with a LONG K loop (ResNet18's last stage at batch 128: 32 tiles of 144 K steps):
@@ -922,10 +938,6 @@ static int launch_halo(ConvDmaParams& p, const HaloGeom& hg, hipStream_t st) {
   return NBDT_OK;
 }
 
-static int cout_tile(int cout) {
-  const int nt32 = cout / 32;
-  return nt32 % 5 == 0 ? 5 : (nt32 % 4 == 0 ? 4 : (nt32 % 2 == 0 ? 2 : 1));
-}
 
 // Fills hg when the pixel tiles of `tile` pixels are whole image rows / whole images and the two halo buffers
 // fit in LDS next to the weight ring.  pad: the LDS image gets rows of gw + 4 slots (conv3x3_pp_kernel<.., PAD = true>).

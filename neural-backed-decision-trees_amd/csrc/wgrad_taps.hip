@@ -1319,7 +1319,16 @@ static int launch_taps(WgradTapsParams& p, hipStream_t st) {
   // not for a CU-budgeted launch: the caller runs an HBM-bound pass beside it (the BatchNorm backward of the CU-sharing
   // schedule), the fold's ~110 MB would compete with exactly that, and the step does not get shorter
   // (profiles/r05_wgrad_store_epilogue_ab.txt: WRN-28-10 at 512 images, where every such launch is budgeted).
-  p.store = (KIND == 3 && ((wgrad_store_epilogue() && p.splits <= 64 && p.d.cu_budget == 0) || deterministic())) ? 1 : 0;
+  // ... and only when the nine taps fill EVERY weight slot exactly once (w_ntaps == 9, w_tap a permutation): plain stores
+  // into an un-zeroed copy would otherwise fold uninitialised workspace into dw (w_ntaps > 9) or lose sums (duplicate
+  // w_tap).  Such descriptors keep the atomics -- into zeroed rows in deterministic mode.
+  bool covers = p.d.w_ntaps == 9;
+  {
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) seen |= 1u << (p.d.w_tap[t] & 31);
+    covers = covers && seen == 0x1ffu;
+  }
+  p.store = (KIND == 3 && covers && ((wgrad_store_epilogue() && p.splits <= 64 && p.d.cu_budget == 0) || deterministic())) ? 1 : 0;
   if (p.store || deterministic()) {
     float* rows = det_rows(st, (size_t)p.splits * dw_elems);
     if (!rows && !deterministic()) {

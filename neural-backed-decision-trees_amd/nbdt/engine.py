@@ -1409,12 +1409,19 @@ class GraphedStep:
         self.engine, self.criterion = engine, criterion
         self.img = img.clone()
         self.targets = targets.clone()
-        for _ in range(warmup):     # allocate every buffer, set kernel attributes, warm the allocator
-            train_step(engine, criterion, self.img, self.targets, lr, momentum, weight_decay)
+        # Warm up and capture on ONE explicit stream: the library's per-(device, stream) workspaces -- K-split
+        # weight-gradient copies, stem weight-gradient rows, split-K partials and tickets -- cannot be allocated inside a
+        # capture, so a launch that meets its stream for the first time there silently takes its fallback form (atomics, no
+        # split).  torch.cuda.graph() without stream= captures on a private stream the warm-up never ran on.
+        self._stream = torch.cuda.Stream(device=self.img.device)
+        self._stream.wait_stream(torch.cuda.current_stream(self.img.device))
+        with torch.cuda.stream(self._stream):
+            for _ in range(warmup):     # allocate every buffer and workspace, set kernel attributes, warm the allocator
+                train_step(engine, criterion, self.img, self.targets, lr, momentum, weight_decay)
         torch.cuda.synchronize()
         self._captured = self._criterion_state()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self._stream):
             self.loss = train_step(engine, criterion, self.img, self.targets, lr, momentum, weight_decay)
             engine.join_side_stream()     # a capture must end with every forked stream joined
 

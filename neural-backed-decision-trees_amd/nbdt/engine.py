@@ -24,6 +24,21 @@ SIDE_STREAM_PRIORITY = 0       # HIP stream priority of the weight-gradient stre
 
 ALIGN = 8  # elements: keeps every parameter 16-byte aligned in the bf16 mirror
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """THE second HIP stream of this process on `device` (weight gradients, derived-weight builds): created once and
+    shared by every engine.  Streams created later in a process land on the main stream's hardware queue in about one
+    of four tries (measured in round 3; seen again in round 6 as one 20 ms engine in ten in scripts that build several
+    engines) -- there the two-stream schedule serialises and a WRN-28-10 step takes 19-20 ms instead of 16.5.  One engine
+    steps at a time, so sharing the stream costs nothing."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
+    return _SIDE_STREAMS[key]
+
 
 def _pad32(c):
     return (c + 31) // 32 * 32
@@ -830,7 +845,7 @@ class WRNEngine(_Engine):
         # (76 KB, 4 waves) fit on one CU together, and the two kernels stall on different things, so running
         # conv.wgrad next to the dgrad / BatchNorm-backward chain instead of in front of it is worth 3.9 % of the
         # step (21.62 -> 20.80 ms, same-box A/B; engine.set_overlap(False) restores the single-stream order).
-        self._side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY)     # engine.set_overlap(False) puts everything back
+        self._side = side_stream(self.device)     # engine.set_overlap(False) puts everything back
         for c in self.convs:                                   # on the caller's stream (profiling passes)
             c.side_stream = self._side
         # BatchNorm-backward passes beside the weight gradients on disjoint CUs: on by default, kept only if the
@@ -1185,7 +1200,7 @@ class ResNetEngine(_Engine):
         self.store.add("linear.weight", (num_classes, cin), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.store.add("linear.bias", (num_classes,), lambda v: v.uniform_(-kb, kb, generator=gen))
         self.finalize()
-        self._side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY)     # weight gradients on a second stream (see WRNEngine)
+        self._side = side_stream(self.device)     # weight gradients on a second stream (see WRNEngine)
         for c in self.convs:
             c.side_stream = self._side
         dev = self.device

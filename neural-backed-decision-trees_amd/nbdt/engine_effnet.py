@@ -17,7 +17,7 @@ import math
 import torch
 
 from nbdt import ops
-from nbdt.engine import _Engine, _pad32
+from nbdt.engine import _Engine, _pad32, side_stream
 
 # (stage stride, [(out_channels, kernel, expansion), ...]) -- pytorchcv get_efficientnet(version="b0")
 B0_STAGES = [
@@ -145,7 +145,7 @@ class EfficientNetEngine(_Engine):
         self.finalize()
         self._step = 0
         self.dropout_seed = seed
-        self._side = torch.cuda.Stream(device=self.device)     # weight gradients on a second stream (see WRNEngine)
+        self._side = side_stream(self.device)     # weight gradients on the process's second stream (see WRNEngine)
         for c in self.convs + self.dws:
             c.side_stream = self._side
 

@@ -330,8 +330,8 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
 }
 
 // The same pass on a FIXED NUMBER OF CUs (nbdt_bn_bwd_apply_cus): `cus` persistent blocks of up to 1024 threads,
-// one per CU (the launch asks for 96 KB of LDS it never touches, so a second block cannot join), two pixels in flight
-// per thread.  An HBM-bound pass needs few CUs -- 64 reach 3.0 TB/s, 96 4.1, all 256 5.6 (probes/cu_share_probe.hip) --
+// one per CU (the launch asks for 96 KB of LDS it never touches, so a second block cannot join), kCusInFlight pixels in
+// flight per thread.  An HBM-bound pass needs few CUs -- 64 reach 3.0 TB/s, 96 4.1, all 256 5.6 (probes/cu_share_probe.hip) --
 // and an MFMA-bound kernel loses less than its share of CUs when it gives some up (the chip is power-limited: 192 CUs
 // deliver 83 % of the 256-CU matrix rate), so the weight gradient of the same unit runs on the other CUs meanwhile.
 // A block of the ordinary launch above is 4 waves and the dispatcher spreads 2048 of them over every CU, where
@@ -343,6 +343,10 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
 // takes k0 / k1 from there; block 0 also writes dsum, accumulates dbeta / dgamma and zeroes `zero_other` -- the
 // OTHER slot buffer of the caller's pair, which nobody touches during this launch (the slots being read here cannot
 // be zeroed before every block has read them; the caller alternates the two buffers).
+#ifndef NBDT_CUS_IN_FLIGHT
+#define NBDT_CUS_IN_FLIGHT 2   // 4 measured equal, 8 slower (profiles/r06_session2_small_abs.txt)
+#endif
+constexpr int kCusInFlight = NBDT_CUS_IN_FLIGHT;   // pixels (16-byte loads per tensor) in flight per thread of the confined passes
 template <bool HAS_ADD, bool FOLD>
 __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
     const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
@@ -400,16 +404,22 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
   };
   const int step = gridDim.x * PY;
   int p = blockIdx.x * PY + py;
-  for (; p + step < g.npix; p += 2 * step) {
-    const int o0 = pad_offset(g, p) + cx * 8, o1 = pad_offset(g, p + step) + cx * 8;
-    const u32x4_t x0 = *(const u32x4_t*)(x + o0), x1 = *(const u32x4_t*)(x + o1);
-    const u32x4_t g0 = *(const u32x4_t*)(gy + o0), g1 = *(const u32x4_t*)(gy + o1);
-    u32x4_t a0 = x0, a1 = x1;
-    if (HAS_ADD) { a0 = *(const u32x4_t*)(gx_add + o0); a1 = *(const u32x4_t*)(gx_add + o1); }
-    one(x0, g0, a0, o0);
-    one(x1, g1, a1, o1);
+  for (; p + (kCusInFlight - 1) * step < g.npix; p += kCusInFlight * step) {
+    int o[kCusInFlight];
+    u32x4_t vx[kCusInFlight], vg[kCusInFlight], va[kCusInFlight];
+#pragma unroll
+    for (int u = 0; u < kCusInFlight; ++u) o[u] = pad_offset(g, p + u * step) + cx * 8;
+#pragma unroll
+    for (int u = 0; u < kCusInFlight; ++u) {
+      vx[u] = *(const u32x4_t*)(x + o[u]);
+      vg[u] = *(const u32x4_t*)(gy + o[u]);
+      va[u] = vx[u];
+      if (HAS_ADD) va[u] = *(const u32x4_t*)(gx_add + o[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kCusInFlight; ++u) one(vx[u], vg[u], va[u], o[u]);
   }
-  if (p < g.npix) {
+  for (; p < g.npix; p += step) {
     const int o0 = pad_offset(g, p) + cx * 8;
     const u32x4_t x0 = *(const u32x4_t*)(x + o0), g0 = *(const u32x4_t*)(gy + o0);
     u32x4_t a0 = x0;
@@ -462,14 +472,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* _
   if (live) {
     const int step = gridDim.x * PY;
     int p = blockIdx.x * PY + py;
-    for (; p + step < g.npix; p += 2 * step) {
-      const int o0 = pad_offset(g, p) + cx * 8, o1 = pad_offset(g, p + step) + cx * 8;
-      const u32x4_t x0 = *(const u32x4_t*)(x + o0), x1 = *(const u32x4_t*)(x + o1);
-      const u32x4_t g0 = *(const u32x4_t*)(gy + o0), g1 = *(const u32x4_t*)(gy + o1);
-      one(x0, g0);
-      one(x1, g1);
+    for (; p + (kCusInFlight - 1) * step < g.npix; p += kCusInFlight * step) {      // (pixels in ascending order: the sums' bits
+      u32x4_t vx[kCusInFlight], vg[kCusInFlight];                                  //  do not depend on kCusInFlight)
+#pragma unroll
+      for (int u = 0; u < kCusInFlight; ++u) {
+        const int o = pad_offset(g, p + u * step) + cx * 8;
+        vx[u] = *(const u32x4_t*)(x + o);
+        vg[u] = *(const u32x4_t*)(gy + o);
+      }
+#pragma unroll
+      for (int u = 0; u < kCusInFlight; ++u) one(vx[u], vg[u]);
     }
-    if (p < g.npix) {
+    for (; p < g.npix; p += step) {
       const int o0 = pad_offset(g, p) + cx * 8;
       one(*(const u32x4_t*)(x + o0), *(const u32x4_t*)(gy + o0));
     }

@@ -361,6 +361,13 @@ class _Engine:
         self._seg_ops = {}
         self.seg_share = True     # ... with bn1's backward beside conv1's weight gradient on disjoint CUs (strided units; "all": every one; False: none)
         self.seg_join = None      # wait for conv2's weight gradient before the slice-list data gradient: "small" (8x8 grids), "all", None
+        # CU sharing, per stage: dense units whose output grid has at least this many pixels take their BatchNorm-backward
+        # sums from the data gradient's epilogue again (the round-1 fused form) and confine only the elementwise pass
+        # (0 = every stage uses the split form).  Where the confined reduce + apply outlast the weight gradient beside them
+        # (32x32: 290-310 us against 250-300), the sums cost less at MFMA price than on the critical chain.
+        self.share_fused_hw = 0
+        self.share_stage_us = {}  # output-grid pixels (ho * wo) -> split_target_us of that stage (absent: set_cu_share's)
+        self.share_fused_target_us = 200.0
 
     def seg_op(self, key, build, sources, sources32, on_side=False):
         """The SegOp `key` (created, and its weights tiled, at first use: a new batch size or image size)."""
@@ -851,6 +858,11 @@ class WRNEngine(_Engine):
         # BatchNorm-backward passes beside the weight gradients on disjoint CUs: on by default, kept only if the
         # calibration before the first backward() finds it faster on this box (set_cu_share(None) turns it off)
         self.set_cu_share(47.0)
+        # per stage (output-grid pixels -> split_target_us): the 32x32 and 16x16 stages are bound by the main stream's
+        # chain (data gradient, then the confined reduce + apply: 290-310 / 225 us against weight gradients of 250-300 / 203),
+        # so their passes get more CUs than one number for all stages gives them: 104 / 120 instead of 96 / 112 beside
+        # the stage-1 weight gradients, 72 instead of 56 in stage 2 (profiles/r06_stage_target_ab.txt: 15.92 -> 15.83 ms)
+        self.share_stage_us = {1024: 170.0, 256: 150.0}
 
     # ---- the shape-changing units on the slice-list kernel (csrc/conv_seg.hip)
     def _seg_conv1(self, u, B, h, w):
@@ -1053,6 +1065,10 @@ class WRNEngine(_Engine):
             # an HBM burst while the matrix pipes wait) into the CU-confined pass beside the weight gradient.
             share = self._cu_share is not None and fuse and (two_streams or self.debug_share_serial)
             split = share and self._share_split[0]
+            fused_here = bool(split and self.share_fused_hw and ho * wo >= self.share_fused_hw and not seg)
+            if fused_here:
+                split = False
+            split_us = self.share_stage_us.get(ho * wo, self._share_split[1])
             if self._cu_share is not None and self._share_split[0] and fuse and not share:
                 # one-stream mode (profiling passes, bench.py's roofline pass) of the split schedule: the same MFMA
                 # kernels as the timed step -- data gradients with their plain epilogue -- and the BatchNorm sums in a
@@ -1060,7 +1076,7 @@ class WRNEngine(_Engine):
                 fuse = False
             if split:
                 u["conv2"].backward_data(g, ga2)
-                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, self.share_bn2_tensors, self._share_split[1])
+                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, self.share_bn2_tensors, split_us)
                 u["bn2"].backward_cus(ga2, t, gt, n2)
                 if self._share_join:
                     self.join_side_stream()
@@ -1068,7 +1084,8 @@ class WRNEngine(_Engine):
                 if not share:
                     u["conv2"].backward_weight(a2, g)
                 u["conv2"].backward_data(g, ga2, bn=u["bn2"], bn_x=t, partials=self.partials(t))
-                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 3) if share else 0
+                n2 = self._share_pair(u["conv2"], a2, g, B * ho * wo * cout, 3,
+                                      self.share_fused_target_us if fused_here else None) if share else 0
                 u["bn2"].backward_fused(ga2, t, gt, self.partials(t), cus=n2)
                 if share and self._share_join:
                     # The next data gradient is one persistent block per CU with a fixed share of the tiles: blocks
@@ -1084,7 +1101,7 @@ class WRNEngine(_Engine):
             if split and u["idconv"] is None:
                 x_in = u["x_in"]
                 u["conv1"].backward_data(gt, ga1)
-                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, self.share_bn1_tensors, self._share_split[1])
+                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, self.share_bn1_tensors, split_us)
                 u["bn1"].backward_cus(ga1, x_in, g_in, n1, gx_add=g)
                 g, h, w = g_in, hi, wi
                 continue
@@ -1093,7 +1110,8 @@ class WRNEngine(_Engine):
                 if not share:
                     u["conv1"].backward_weight(a1, gt)
                 u["conv1"].backward_data(gt, ga1, bn=u["bn1"], bn_x=x_in, partials=self.partials(x_in))
-                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 4) if share else 0
+                n1 = self._share_pair(u["conv1"], a1, gt, B * hi * wi * cin, 4,
+                                      self.share_fused_target_us if fused_here else None) if share else 0
                 u["bn1"].backward_fused(ga1, x_in, g_in, self.partials(x_in), gx_add=g, cus=n1)
                 g, h, w = g_in, hi, wi
                 continue
@@ -1112,7 +1130,7 @@ class WRNEngine(_Engine):
                     self._seg_dgrad(u, B, hi, wi)([gt, g], ga1)
                     desc = u["conv1"].s2d_plan(B, hi, wi)[1] if s == 2 else u["conv1"].plan(B, hi, wi)[3]
                     gbps, _, lo, hi_cus = self._cu_share
-                    budget, n1 = ops.plan_cu_share(desc, B * hi * wi * cin, self.share_bn2_tensors, gbps, self._share_split[1], lo, hi_cus)
+                    budget, n1 = ops.plan_cu_share(desc, B * hi * wi * cin, self.share_bn2_tensors, gbps, split_us, lo, hi_cus)
                     if s == 2:
                         u["conv1"].backward_weight_s2d(a1, gt, hi, wi, cu_budget=budget)
                         u["idconv"].backward_weight_s2d(a1, g, hi, wi)

@@ -485,6 +485,22 @@ int nbdt_bn_act_bwd_apply(const void* gu, const void* x, const float* save_mean,
                           const float* gamma, const float* beta, int32_t act, const void* gx_add, int32_t B, int32_t H,
                           int32_t W, int32_t C, float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx,
                           void* stream);
+/* Squeeze-and-excitation backward with ONE reduction pass over (gu, x) instead of two (nbdt_bn_act_pool(mul = gu) for
+ * dL/dgate, then nbdt_bn_act_bwd's sums).  The gradient entering the activation, g_a = gu*gate[b][c] + gpool[b][c]/HW, is
+ * linear in (gate, gpool) per image and channel, so the BatchNorm-backward sums follow from five per-(image, channel) sums
+ * that do not need gpool: sums[5][B][C] fp32 += { sum gu*act(y), sum gu*act'(y), sum gu*act'(y)*xhat, sum act'(y),
+ * sum act'(y)*xhat } over the image's pixels, y = bn(x).  `sums` must be ZERO on entry (allocate it zeroed once); sums[0]
+ * is dL/dgate: feed it to nbdt_se_gate_bwd, then nbdt_bn_act_se_bwd_apply folds sums[1..4] with gate / gpool into dsum
+ * (dgamma, dbeta accumulate), ZEROES `sums` again for the next use (no memset launch per call) and runs
+ * nbdt_bn_act_bwd's elementwise pass.  Replaces the autograd of pytorchcv's SEBlock scaling + BatchNorm + swish
+ * (reference: nbdt/models/__init__.py:3).  Not available in deterministic mode (atomics across pixel slices). */
+int nbdt_bn_act_se_sums(const void* gu, const void* x, const float* save_mean, const float* save_rstd,
+                        const float* gamma, const float* beta, int32_t act, int32_t B, int32_t H, int32_t W, int32_t C,
+                        float* sums, void* stream);
+int nbdt_bn_act_se_bwd_apply(const void* gu, const float* gate, const float* gpool, float* sums, const void* x,
+                             const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
+                             int32_t act, int32_t B, int32_t H, int32_t W, int32_t C, float* dsum, float* dgamma,
+                             float* dbeta, void* gx, void* stream);
 int nbdt_dwconv_bwd_weight(const void* x, const void* gy, int32_t B, int32_t H, int32_t W, int32_t C,
                            int32_t k, int32_t stride, float* dw, void* stream);
 /* SEBlock gate: gate[b][c] = sigmoid(W2 swish(W1 pooled[b] + b1) + b2) for c < C_real, 0 above.

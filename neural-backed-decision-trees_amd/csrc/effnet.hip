@@ -298,6 +298,94 @@ __global__ __launch_bounds__(256) void mb_bwd_finalize_kernel(float* __restrict_
   }
 }
 
+// Squeeze-and-excitation backward in ONE pass over (gu, x).  The gradient entering the activation of the depthwise
+// output is g_a = gu * gate[b,c] + gpool[b,c] / HW, and gpool comes out of the SE branch's backward, which needs
+// dL/dgate[b,c] = sum_hw gu * act(y) first -- so rounds 1-5 read (gu, x) three times: dL/dgate, then the BatchNorm
+// sums of g_y = g_a * act'(y), then the elementwise pass.  But g_y is LINEAR in (gate, gpool) per image and channel:
+//   sum g_y      = sum_b gate[b,c] * S1[b,c] + gpool[b,c] / HW * S3[b,c]        S1 = sum_hw gu * act'(y)   S3 = sum_hw act'(y)
+//   sum g_y*xhat = sum_b gate[b,c] * S2[b,c] + gpool[b,c] / HW * S4[b,c]        S2 = sum_hw gu * act'(y) * xhat   S4 = sum_hw act'(y) * xhat
+// so this kernel adds S0 = dL/dgate and S1..S4 per (image, channel) into sums[5][B][C] (zero on entry) and
+// mb_se_finalize_kernel turns them into the BatchNorm sums once gpool exists -- and zeroes the buffer again for the next
+// user, like the BatchNorm slots' finalize kernels do: one pass over the two tensors less, no memset launch.
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void mb_se_sums_kernel(const bf16_t* __restrict__ gu,
+                                                              const bf16_t* __restrict__ x, const float* mean,
+                                                              const float* rstd, const float* gamma,
+                                                              const float* beta, MbGeom g, int ppt,
+                                                              float* __restrict__ sums) {
+  extern __shared__ float lds[];
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
+  BnRegs bn;
+  load_bn(bn, mean, rstd, gamma, beta, cx);
+  float mu[8], rs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    mu[i] = mean[cx * 8 + i];
+    rs[i] = rstd[cx * 8 + i];
+  }
+  float acc[5][8];
+#pragma unroll
+  for (int q = 0; q < 5; ++q)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[q][i] = 0.f;
+  const int p0 = blockIdx.x * g.PY * ppt + py;
+  for (int k = 0; k < ppt; ++k) {
+    const int p = p0 + k * g.PY;
+    if (p >= g.hw) break;
+    const int o = pix_off(g, b, p, cx);
+    float fx[8], fg[8];
+    unpack8(*(const u32x4_t*)(x + o), fx);
+    unpack8(*(const u32x4_t*)(gu + o), fg);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float y = fx[i] * bn.sc[i] + bn.sh[i];
+      const float xh = (fx[i] - mu[i]) * rs[i];
+      const float d = act_bwd<ACT>(y), gd = fg[i] * d;
+      acc[0][i] += fg[i] * act_fwd<ACT>(y);
+      acc[1][i] += gd;
+      acc[2][i] += gd * xh;
+      acc[3][i] += d;
+      acc[4][i] += d * xh;
+    }
+  }
+  const size_t plane = (size_t)g.B * g.C;
+  float* dst = sums + (size_t)b * g.C;
+  block_fold<5>(acc, cx, py, g.c8, g.PY, lds, [&](int q, int c, float s) { atomicAdd(dst + q * plane + c, s); });
+}
+
+// sums[5][B][C] + gate, gpool -> the BatchNorm-backward sums (dsum[0..C) = sum g_y, dsum[C..2C) = sum g_y * xhat; dbeta,
+// dgamma accumulate).  64 channels x 4 image lanes per block; a channel's sum is its 4 lane partials in lane order.
+__global__ __launch_bounds__(256) void mb_se_finalize_kernel(float* __restrict__ sums,
+                                                             const float* __restrict__ gate,
+                                                             const float* __restrict__ gpool, int B, int C,
+                                                             float inv_hw, float* __restrict__ dsum,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float part[2][4][64];
+  const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const size_t plane = (size_t)B * C;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C)
+    for (int b = lane; b < B; b += 4) {
+      const size_t o = (size_t)b * C + c;
+      const float gt = gate[o], gp = gpool[o] * inv_hw;
+      s0 += gt * sums[plane + o] + gp * sums[3 * plane + o];
+      s1 += gt * sums[2 * plane + o] + gp * sums[4 * plane + o];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sums[q * plane + o] = 0.f;      // (dL/dgate, plane 0, was consumed by nbdt_se_gate_bwd)
+    }
+  part[0][lane][cl] = s0;
+  part[1][lane][cl] = s1;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    const float t0 = ((part[0][0][cl] + part[0][1][cl]) + part[0][2][cl]) + part[0][3][cl];
+    const float t1 = ((part[1][0][cl] + part[1][1][cl]) + part[1][2][cl]) + part[1][3][cl];
+    dsum[c] = t0;
+    dsum[C + c] = t1;
+    if (dbeta) dbeta[c] += t0;
+    if (dgamma) dgamma[c] += t1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // depthwise convolution, weights fp32 [k*k][C]; x padded [B][H+2][W+2][C], y padded [B][Ho+2][Wo+2][C]
 struct DwGeom {
@@ -888,8 +976,8 @@ static int bn_act_bwd_impl(const void* gu, const float* gate, const float* gpool
                            const float* save_mean, const float* save_rstd, const float* gamma, const float* beta,
                            int32_t act, const void* gx_add, int32_t B, int32_t H, int32_t W, int32_t C,
                            float* scratch, float* dsum, float* dgamma, float* dbeta, void* gx, void* stream,
-                           bool sums_ready) {
-  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && scratch && dsum && gx, "null argument");
+                           bool sums_ready, bool dsum_ready = false) {
+  NBDT_REQUIRE(x && save_mean && save_rstd && gamma && beta && (scratch || dsum_ready) && dsum && gx, "null argument");
   NBDT_REQUIRE(gu || (gpool && !gate), "need an upstream gradient tensor or a pooled gradient");
   NBDT_REQUIRE(!gate || (gu && gpool), "the SE form needs gu, gate and gpool");
   NBDT_REQUIRE(act >= 0 && act <= 2, "unknown activation");
@@ -898,7 +986,7 @@ static int bn_act_bwd_impl(const void* gu, const float* gate, const float* gpool
   hipStream_t st = (hipStream_t)stream;
   const bool se = gate != nullptr, pool = gu == nullptr;
   NBDT_REQUIRE(!(pool && gx_add), "pooled form has no gx_add");
-  if (!sums_ready) {      // (sums_ready: the producing kernel -- nbdt_dwconv_bwd_data_bn -- already filled the slots)
+  if (!sums_ready && !dsum_ready) {      // (sums_ready: the producing kernel -- nbdt_dwconv_bwd_data_bn -- already filled the slots)
     const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
     const dim3 grid(g.slices, B), blk(g.threads);
     const size_t shmem = (size_t)g.threads * 16 * sizeof(float);
@@ -918,8 +1006,10 @@ static int bn_act_bwd_impl(const void* gu, const float* gate, const float* gpool
     rc = slot_finish(st, tgt, nblk, 2 * (size_t)C, scratch);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(mb_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
-  NBDT_LAUNCH_CHECK();
+  if (!dsum_ready) {      // (dsum_ready: nbdt_bn_act_se_bwd_apply's own finalize kernel already wrote dsum / dgamma / dbeta)
+    hipLaunchKernelGGL(mb_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, C, dsum, dgamma, dbeta);
+    NBDT_LAUNCH_CHECK();
+  }
   {
     const MbGeom g = mb_geom(B, H, W, C, kPpt);
     const dim3 grid(g.slices, B), blk(g.threads);
@@ -953,6 +1043,41 @@ extern "C" int nbdt_bn_act_bwd_apply(const void* gu, const void* x, const float*
   NBDT_REQUIRE(gu != nullptr, "null upstream gradient");
   return bn_act_bwd_impl(gu, nullptr, nullptr, x, save_mean, save_rstd, gamma, beta, act, gx_add, B, H, W, C, scratch,
                          dsum, dgamma, dbeta, gx, stream, true);
+}
+
+extern "C" int nbdt_bn_act_se_sums(const void* gu, const void* x, const float* save_mean, const float* save_rstd,
+                                   const float* gamma, const float* beta, int32_t act, int32_t B, int32_t H, int32_t W,
+                                   int32_t C, float* sums, void* stream) {
+  NBDT_REQUIRE(gu && x && save_mean && save_rstd && gamma && beta && sums, "null argument");
+  NBDT_REQUIRE(act >= 0 && act <= 2, "unknown activation");
+  NBDT_REQUIRE(!deterministic(), "nbdt_bn_act_se_sums adds its pixel slices with atomics: use nbdt_bn_act_pool + nbdt_bn_act_bwd in deterministic mode");
+  int rc = check_mb(B, H, W, C);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const MbGeom g = mb_geom(B, H, W, C, 2 * kPpt);
+  const dim3 grid(g.slices, B), blk(g.threads);
+  const size_t shmem = (size_t)g.threads * 40 * sizeof(float);
+#define NBDT_GO(A)                                                                                              \
+  hipLaunchKernelGGL((mb_se_sums_kernel<A>), grid, blk, shmem, st, (const bf16_t*)gu, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, 2 * kPpt, sums)
+  NBDT_ACT_SWITCH(act, NBDT_GO);
+#undef NBDT_GO
+  NBDT_LAUNCH_CHECK();
+  return NBDT_OK;
+}
+
+extern "C" int nbdt_bn_act_se_bwd_apply(const void* gu, const float* gate, const float* gpool, float* sums,
+                                        const void* x, const float* save_mean, const float* save_rstd,
+                                        const float* gamma, const float* beta, int32_t act, int32_t B, int32_t H,
+                                        int32_t W, int32_t C, float* dsum, float* dgamma, float* dbeta, void* gx,
+                                        void* stream) {
+  NBDT_REQUIRE(gu && gate && gpool && sums && dsum, "null argument");
+  int rc = check_mb(B, H, W, C);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mb_se_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, sums, gate, gpool,
+                     B, C, 1.f / (float)(H * W), dsum, dgamma, dbeta);
+  NBDT_LAUNCH_CHECK();
+  return bn_act_bwd_impl(gu, gate, gpool, x, save_mean, save_rstd, gamma, beta, act, nullptr, B, H, W, C, nullptr, dsum,
+                         dgamma, dbeta, gx, stream, false, true);
 }
 
 static int check_dw(int B, int H, int W, int C, int k, int stride) {

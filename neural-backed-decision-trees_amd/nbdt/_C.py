@@ -169,6 +169,9 @@ SIGNATURES = {
     "nbdt_dwconv_bwd_data_bn": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nbdt_bn_act_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32,
                                       _P, _P, _P, _P, _P, _P]),
+    "nbdt_bn_act_se_sums": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "nbdt_bn_act_se_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         _P, _P, _P, _P, _P]),
     "nbdt_dwconv_bwd_weight": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "nbdt_se_gate_fwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_se_gate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P,

@@ -806,6 +806,13 @@ class _Engine:
             self._bufs[k] = torch.empty(shape, dtype=torch.float32, device=self.device)
         return self._bufs[k]
 
+    def _zeroed(self, key, shape):
+        """fp32 accumulator under the zero-on-entry / re-zeroed-by-the-last-reader contract (like the BatchNorm slots)."""
+        k = (key, "zeroed") + tuple(shape)
+        if k not in self._bufs:
+            self._bufs[k] = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        return self._bufs[k]
+
 
 class WRNEngine(_Engine):
     """Pre-activation WideResNet (pytorchcv ``CIFARWRN``: wrn28_10_cifar10/100, reference

@@ -145,6 +145,7 @@ class EfficientNetEngine(_Engine):
         self.finalize()
         self._step = 0
         self.dropout_seed = seed
+        self.fuse_se_bwd = True   # SE backward: dL/dgate and bn2's backward sums from ONE pass over (gd, d_raw)
         self._side = side_stream(self.device)     # weight gradients on the process's second stream (see WRNEngine)
         for c in self.convs + self.dws:
             c.side_stream = self._side
@@ -354,14 +355,27 @@ class EfficientNetEngine(_Engine):
             u["conv3"].backward_data(gp, gd)
             # squeeze-and-excitation + BatchNorm/swish of the depthwise output (gd rewritten in place)
             bn = u["bn2"]
-            dgate, gpool = self._vec(f"dgate{tag}", B, mid), self._vec(f"gpool{tag}", B, mid)
-            ops.bn_act_pool(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, dgate, act=ACT, mul=gd, scale=1.0)
-            u["se"].backward(dgate, self._vec(k + ".gate", B, mid), self._vec(k + ".pre1", B, u["se"].mid),
+            gpool = self._vec(f"gpool{tag}", B, mid)
+            gate = self._vec(k + ".gate", B, mid)
+            one_pass = self.fuse_se_bwd and gd.dtype == torch.bfloat16 and not ops.is_deterministic()
+            if one_pass:
+                # dL/dgate AND what bn2's backward sums are linear in, in one pass over (gd, d_raw): the reduction pass
+                # of bn_act_bwd (a second read of both tensors) becomes a [B, C]-sized fold once gpool exists
+                sums = self._zeroed(f"se_sums{tag}", (5, B, mid))     # zero on entry, re-zeroed by its last reader
+                ops.bn_act_se_sums(gd, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, sums, act=ACT)
+                dgate = sums[0]
+            else:
+                dgate = self._vec(f"dgate{tag}", B, mid)
+                ops.bn_act_pool(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, dgate, act=ACT, mul=gd, scale=1.0)
+            u["se"].backward(dgate, gate, self._vec(k + ".pre1", B, u["se"].mid),
                              self._vec(k + ".pooled", B, mid), self._vec("dpre2", B, mid),
                              self._vec("dpre1", B, u["se"].mid), gpool)
-            ops.bn_act_bwd(gd, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
-                           st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT,
-                           gate=self._vec(k + ".gate", B, mid), gpool=gpool)
+            if one_pass:
+                ops.bn_act_se_bwd_apply(gd, gate, gpool, sums, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, bn.dsum,
+                                        st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT)
+            else:
+                ops.bn_act_bwd(gd, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
+                               st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT, gate=gate, gpool=gpool)
             x_in = u["x_in"]
             if u["conv1"] is not None:
                 e_raw = self.buf(k + ".e_raw", B, hi, wi, mid)

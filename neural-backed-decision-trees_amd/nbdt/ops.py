@@ -675,6 +675,22 @@ def bn_act_bwd_apply(gu, x, mean, rstd, gamma, beta, scratch, dsum, dgamma, dbet
                                       stream_ptr(x.device)))
 
 
+def bn_act_se_sums(gu, x, mean, rstd, gamma, beta, sums, act=ACT_SWISH):
+    """One pass over (gu, x): sums[5][B][C] = dL/dgate and the four per-(image, channel) sums the BatchNorm backward of the
+    SE-scaled activation is linear in (include/nbdt_hip.h: nbdt_bn_act_se_sums).  bf16 production path only."""
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_act_se_sums(ptr(gu), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, B, H, W, C,
+                                    ptr(sums), stream_ptr(x.device)))
+
+
+def bn_act_se_bwd_apply(gu, gate, gpool, sums, x, mean, rstd, gamma, beta, dsum, dgamma, dbeta, gx, act=ACT_SWISH):
+    """Fold bn_act_se_sums' sums with gate / gpool into the BatchNorm-backward sums, then bn_act_bwd's elementwise pass."""
+    B, H, W, C = _dims(x)
+    check(lib().nbdt_bn_act_se_bwd_apply(ptr(gu), ptr(gate), ptr(gpool), ptr(sums), ptr(x), ptr(mean), ptr(rstd),
+                                         ptr(gamma), ptr(beta), act, B, H, W, C, ptr(dsum), ptr(dgamma), ptr(dbeta),
+                                         ptr(gx), stream_ptr(x.device)))
+
+
 def dwconv_bwd_weight(x, gy, dw, k, stride):
     B, H, W, C = _dims(x)
     if _ref(x):

@@ -198,6 +198,60 @@ def test_bn_act_apply_pool_and_backward_forms(C, H, W, act):
         assert scratch.abs().max().item() == 0, "scratch must be left zeroed"
 
 
+@pytest.mark.parametrize("B,C,H,W", [(4, 32, 8, 8), (3, 96, 14, 14), (5, 672, 7, 7), (2, 1152, 7, 7), (2, 160, 28, 28)])
+def test_se_backward_in_one_reduction_pass(B, C, H, W):
+    """nbdt_bn_act_se_sums + nbdt_bn_act_se_bwd_apply against autograd through swish(bn(x)) * gate and the pooled branch,
+    and against the three-pass form (nbdt_bn_act_pool(mul) + nbdt_bn_act_bwd) on the same inputs: dL/dgate, dgamma, dbeta
+    to fp32 summation noise, the input gradient to one bf16 rounding."""
+    g = torch.Generator().manual_seed(B * C + H)
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 2 + 0.3)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    gate = torch.rand(B, C, generator=g)
+    gu = _bf(torch.randn(B, C, H, W, generator=g))
+    gpool = torch.randn(B, C, generator=g)
+    xp, gup = _padded_from(x), _padded_from(gu)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    scratch = torch.zeros(ops.BN_SLOTS * 2 * 2048, device=DEV)
+    ops.bn_stats(xp, scratch, mean, rstd)
+    gd, bd, gate_d, gpool_d = gamma.to(DEV), beta.to(DEV), gate.to(DEV), gpool.to(DEV)
+    # autograd reference
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = _swish(F.batch_norm(xr, None, None, gr, br, True, 0.0, 1e-5))
+    (a * gate[:, :, None, None]).backward(gu, retain_graph=True)
+    a.mean((2, 3)).backward(gpool)
+    want_dgate = (a.detach() * gu).sum((2, 3))
+    # one-pass form
+    sums = torch.zeros((5, B, C), device=DEV)      # zero on entry; the apply call leaves it zero again
+    ops.bn_act_se_sums(gup, xp, mean, rstd, gd, bd, sums)
+    dgate1 = sums[0].clone()
+    assert (dgate1.cpu() - want_dgate).abs().max().item() < 2e-3 * max(1.0, want_dgate.abs().max().item())
+    dsum, dgamma, dbeta = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx = ops.padded(B, H, W, C, DEV)
+    ops.bn_act_se_bwd_apply(gup, gate_d, gpool_d, sums, xp, mean, rstd, gd, bd, dsum, dgamma, dbeta, gx)
+    scale = xr.grad.abs().max().item()
+    assert (_nchw(gx) - xr.grad).abs().max().item() < 2e-2 * scale + 1e-3
+    assert (dgamma.cpu() - gr.grad).abs().max().item() < 5e-3 * gr.grad.abs().max().item() + 1e-3
+    assert (dbeta.cpu() - br.grad).abs().max().item() < 5e-3 * br.grad.abs().max().item() + 1e-3
+    assert sums.abs().max().item() == 0, "the sums buffer must be left zeroed"
+    # three-pass form on the same inputs
+    dgate3 = torch.empty(B, C, device=DEV)
+    ops.bn_act_pool(xp, mean, rstd, gd, bd, dgate3, mul=gup, scale=1.0)
+    dsum3, dgamma3, dbeta3 = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx3 = ops.padded(B, H, W, C, DEV)
+    ops.bn_act_bwd(gup, xp, mean, rstd, gd, bd, scratch, dsum3, dgamma3, dbeta3, gx3, gate=gate_d, gpool=gpool_d)
+    assert (dgate1 - dgate3).abs().max().item() < 1e-4 * max(1.0, dgate3.abs().max().item())
+    assert (dsum - dsum3).abs().max().item() < 1e-4 * max(1.0, dsum3.abs().max().item())
+    assert (gx.float() - gx3.float()).abs().max().item() <= 2 ** -7 * gx3.float().abs().max().item()
+    # deterministic mode refuses the atomics form (the engine takes the three-pass form there)
+    ops.set_deterministic(True)
+    try:
+        with pytest.raises(Exception):
+            ops.bn_act_se_sums(gup, xp, mean, rstd, gd, bd, sums)
+    finally:
+        ops.set_deterministic(False)
+
+
 @pytest.mark.parametrize("C,Cr,S", [(32, 32, 8), (160, 144, 6), (1152, 1152, 48)])
 def test_se_gate_forward_backward(C, Cr, S):
     g = torch.Generator().manual_seed(C + S)

@@ -367,6 +367,7 @@ class _Engine:
         # (32x32: 290-310 us against 250-300), the sums cost less at MFMA price than on the critical chain.
         self.share_fused_hw = 0
         self.share_stage_us = {}  # output-grid pixels (ho * wo) -> split_target_us of that stage (absent: set_cu_share's)
+        self.share_scale_batch = True   # ... scaled by batch / 512 (False: rounds 3-5, the same microseconds at every batch)
         self.share_fused_target_us = 200.0
 
     def seg_op(self, key, build, sources, sources32, on_side=False):
@@ -524,6 +525,13 @@ class _Engine:
                                                            max(8, int(min_cus)), int(max_cus))
         self._share_calibrated = not calibrate
 
+    def _split_us(self, grid_pixels, B):
+        """Time budget of the confined reduce + apply of a stage whose output grid has `grid_pixels` pixels: share_stage_us
+        (or set_cu_share's split_target_us), quoted at 512 images -- the weight gradient beside the pass lasts in proportion
+        to the batch, so the pass's budget does too and the CU split does not depend on the batch (a 256-image shard with
+        512-image microseconds gave its passes half the CUs: 10.6 instead of 9.3 ms per step)."""
+        return self.share_stage_us.get(grid_pixels, self._share_split[1]) * (B / 512.0 if self.share_scale_batch else 1.0)
+
     def _share_plan(self, conv, x, elements, tensors, us=None):
         """(weight-gradient descriptor, its CU budget, CUs for the elementwise pass of `tensors` tensors of `elements`
         bf16 that runs beside it)."""
@@ -582,7 +590,7 @@ class _Engine:
         # (plumbing: a one-off fill so the MFMAs see real data -- from a private generator: the caller's global
         # RNG stream is not advanced by a calibration)
         ops.interior(g).normal_(0.0, 1e-3, generator=torch.Generator(device=self.device).manual_seed(0x5eed))
-        split, split_us = self._share_split
+        split, split_us = self._share_split[0], self._split_us(h * w, B)
         elements = B * h * w * cout
         desc, budget, n = self._share_plan(conv, a2, elements, 5 if split else 3, split_us if split else None)
         main = torch.cuda.current_stream(self.device)
@@ -1075,7 +1083,7 @@ class WRNEngine(_Engine):
             fused_here = bool(split and self.share_fused_hw and ho * wo >= self.share_fused_hw and not seg)
             if fused_here:
                 split = False
-            split_us = self.share_stage_us.get(ho * wo, self._share_split[1])
+            split_us = self._split_us(ho * wo, B)
             if self._cu_share is not None and self._share_split[0] and fuse and not share:
                 # one-stream mode (profiling passes, bench.py's roofline pass) of the split schedule: the same MFMA
                 # kernels as the timed step -- data gradients with their plain epilogue -- and the BatchNorm sums in a

@@ -22,6 +22,8 @@ x = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
 y = torch.randint(0, 10, (args.batch,), generator=g).to(dev)
 eng = E.WRNEngine(num_classes=10, blocks=28, width_factor=10, device=dev, seed=0)
 eng.set_cu_share(47.0, calibrate=False)
+if os.environ.get("AB_NO_BATCH_SCALE"):
+    eng.share_scale_batch = False
 for _ in range(5):
     E.train_step(eng, crit, x, y, 0.01)
 B = args.batch

@@ -509,11 +509,16 @@ int nbdt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, cons
                      const float* b2, int32_t B, int32_t C, int32_t C_real, int32_t S, float* pre1,
                      float* gate, void* stream);
 /* dgate [B][C] -> gpool [B][C] (gradient of the pooled mean) and += dW1, db1, dW2, db2;
- * dpre2 [B][C_real], dpre1 [B][S]: workspaces */
+ * dpre2 [B][C_real], dpre1 [B][S]: workspaces.  dw1 = db1 = dw2 = db2 = NULL: the data part only -- the parameter
+ * gradients (which feed nothing but the optimizer) are then the caller's to launch, e.g. on a second stream, with
+ * nbdt_se_param_grad on the dpre2 / dpre1 this call left (nbdt_version() >= 108). */
 int nbdt_se_gate_bwd(const float* dgate, const float* gate, const float* pre1, const float* pooled,
                      const float* w1, const float* w2, int32_t B, int32_t C, int32_t C_real, int32_t S,
                      float* dpre2, float* dpre1, float* gpool, float* dw1, float* db1, float* dw2,
                      float* db2, void* stream);
+int nbdt_se_param_grad(const float* dpre2, const float* dpre1, const float* pre1, const float* pooled,
+                       int32_t B, int32_t C, int32_t C_real, int32_t S, float* dw1, float* db1, float* dw2,
+                       float* db2, void* stream);
 /* nn.Dropout(p) on n fp32 values: mask[i] in {0,1} from a counter hash of (seed, i); y = x*mask/(1-p) */
 int nbdt_dropout_fwd(const float* x, int64_t n, float p, uint32_t seed, uint8_t* mask, float* y,
                      void* stream);

@@ -20,7 +20,7 @@
     (defined(NBDT_WPP_NO_EPI) || defined(NBDT_WKS_NO_EXCHANGE) || defined(NBDT_WKS_DMA_IN_M) || defined(NBDT_WPP_MIN_STAGES) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
      defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) || defined(NBDT_PP_NO_PAD) ||                    \
      defined(NBDT_HALO_NO_ACCUMULATE) || defined(NBDT_DW_TARGET) || defined(NBDT_DW_U) || defined(NBDT_HEAD_SPB) ||    \
-     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) ||                       \
+     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) || defined(NBDT_NO_XCD_CONTIGUOUS) || defined(NBDT_CUS_IN_FLIGHT) ||                      \
      (defined(NBDT_HEAD_SKIP) && (NBDT_HEAD_SKIP + 0) != 0) || (defined(NBDT_PP_ABLATE) && (NBDT_PP_ABLATE + 0) != 0) || \
      (defined(NBDT_PP_SCHED) && (NBDT_PP_SCHED + 0) != 0) || (defined(NBDT_PP_TIMING) && (NBDT_PP_TIMING + 0) != 0) ||  \
      (defined(NBDT_WPP_TIMING) && (NBDT_WPP_TIMING + 0) != 0) || (defined(NBDT_SEG_TIMING) && (NBDT_SEG_TIMING + 0) != 0) || (defined(NBDT_RULES_TIMING) && (NBDT_RULES_TIMING + 0) != 0))

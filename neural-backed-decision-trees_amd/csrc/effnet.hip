@@ -57,6 +57,20 @@ __device__ __forceinline__ int pix_off(const MbGeom& g, int b, int p, int cx) {
   return b * g.img + (h + 1) * g.row + (w + 1) * g.C + cx * 8;
 }
 
+// Thread blocks go to the 8 XCDs round-robin by linear index (MI355X_MICROARCH.md: block b runs on XCD b % 8), each
+// with its own L2: linear neighbours -- adjacent rows of one image in the depthwise kernels, which share K - 1 of their
+// K input rows -- never share a cache, and every shared row crossed the fabric once per reader (rocprofv3 FETCH_SIZE:
+// 2.4-3.7x the input bytes per depthwise launch, profiles/r06_c5_traffic_by_kernel_before.txt).  This maps XCD i's
+// blocks (linear index i, i + 8, ...) to ONE contiguous logical range, so neighbours in the logical order run on the
+// same XCD at about the same time.  A bijection on [0, total) for any total; only speed depends on the dispatch order.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
+#ifdef NBDT_NO_XCD_CONTIGUOUS      // timing-only builds (scratch/build_variants.sh): the dispatch order of rounds 2-5
+  return lin;
+#endif
+  const unsigned q = total >> 3, r = total & 7u, x = lin & 7u, k = lin >> 3;
+  return x * q + (x < r ? x : r) + k;
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
 template <int ACT>
@@ -416,8 +430,9 @@ __global__ __launch_bounds__(kThreads) void dw_row_kernel(const bf16_t* __restri
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
   constexpr int PAD = K / 2, SPAN = TW * S + K - S;
-  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = blockIdx.y;
-  int item = blockIdx.x * PY + py;
+  const unsigned lb = xcd_contiguous(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);   // (image, row block)
+  const int cx = threadIdx.x % g.c8, py = threadIdx.x / g.c8, b = (int)(lb / gridDim.x);
+  int item = (int)(lb % gridDim.x) * PY + py;
   const bool live = item < g.H * nseg;
   if (!STATS && !live) return;
   item = live ? item : 0;                    // STATS: idle threads still take part in the block fold
@@ -563,9 +578,10 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_data_kernel(const bf16_t* __r
                                                                const float* __restrict__ w, MbGeom in, int Ho,
                                                                int Wo, int k, int stride, int pad, int ppt,
                                                                bf16_t* __restrict__ gx) {
-  const int cx = threadIdx.x % in.c8, py = threadIdx.x / in.c8, b = blockIdx.y;
+  const unsigned lb = xcd_contiguous(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+  const int cx = threadIdx.x % in.c8, py = threadIdx.x / in.c8, b = (int)(lb / gridDim.x);
   const int rowo = (Wo + 2) * in.C, imgo = (Ho + 2) * rowo;
-  const int p0 = blockIdx.x * in.PY * ppt + py;
+  const int p0 = (int)(lb % gridDim.x) * in.PY * ppt + py;
   for (int q = 0; q < ppt; ++q) {
     const int p = p0 + q * in.PY;
     if (p >= in.hw) break;
@@ -609,8 +625,9 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_data_s2_row_kernel(const bf16
                                                                       int Wo, int nseg, int PY, bf16_t* __restrict__ gx) {
   // gradient columns wo = wi0/2 - 1 + j that reach the segment: tap s = t + PAD + 2 - 2 j in [0, K) for some t in [0, TW)
   constexpr int PAD = K / 2, J0 = PAD == 1 ? 1 : 0, J1 = (TW + PAD + 1) / 2, SPAN = J1 - J0 + 1;
-  const int cx = threadIdx.x % in.c8, py = threadIdx.x / in.c8, b = blockIdx.y;
-  const int item = blockIdx.x * PY + py;
+  const unsigned lb = xcd_contiguous(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+  const int cx = threadIdx.x % in.c8, py = threadIdx.x / in.c8, b = (int)(lb / gridDim.x);
+  const int item = (int)(lb % gridDim.x) * PY + py;
   if (item >= in.H * nseg) return;
   const int hi = item / nseg;
   const int wi0 = (item - hi * nseg) * TW;
@@ -676,8 +693,13 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* _
                                                                  float* __restrict__ dw, long long row_stride) {
   extern __shared__ float lds[];
   const MbGeom& g = d.out;
-  const int cb = blockIdx.x % cblocks, rb = blockIdx.x / cblocks;
-  const int cxl = threadIdx.x % CB, py = threadIdx.x / CB, r = blockIdx.z;
+  // logical order: kernel row r fastest (the K blocks of one (rows, channels, batch chunk) read the same gradient rows and
+  // input rows one apart), then the x index, then the batch chunk -- contiguous per XCD (xcd_contiguous)
+  const unsigned lb = xcd_contiguous(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                                     gridDim.x * gridDim.y * gridDim.z);
+  const int r = (int)(lb % K), bx = (int)((lb / K) % gridDim.x), by = (int)(lb / (K * gridDim.x));
+  const int cb = bx % cblocks, rb = bx / cblocks;
+  const int cxl = threadIdx.x % CB, py = threadIdx.x / CB;
   const int cx = cb * CB + cxl;
   const bool live = cx < g.c8;
   constexpr int PAD = K / 2;
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* _
     for (int i = 0; i < 8; ++i) acc[s][i] = 0.f;
   const int ho = rb * PY + py;
   const int hi = ho * S + r - PAD;
-  const int b0 = blockIdx.y * bchunk;
+  const int b0 = by * bchunk;
   const int b1 = b0 + bchunk < g.B ? b0 + bchunk : g.B;
   if (live && ho < g.H && hi >= 0 && hi < d.Hi) {
     for (int b = b0; b < b1; ++b) {    // images of this block's batch chunk: one fold + atomics for all
@@ -734,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void dw_bwd_weight_kernel(const bf16_t* _
     }
   }
   // row_stride: 0, or (deterministic mode) K*K*C: a zeroed copy of dw per (row block, batch chunk), folded in order
-  float* dst = dw + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * row_stride + (size_t)r * K * g.C;
+  float* dst = dw + (size_t)(bx + by * gridDim.x) * row_stride + (size_t)r * K * g.C;
   block_fold<K>(acc, cxl, py, CB, PY, lds, [&](int s, int c, float v) {
     if (cb * CB * 8 + c < g.C) atomicAdd(dst + (size_t)s * g.C + cb * CB * 8 + c, v);   // (the last channel block may be short)
   });
@@ -1228,14 +1250,24 @@ extern "C" int nbdt_se_gate_bwd(const float* dgate, const float* gate, const flo
                                 const float* w1, const float* w2, int32_t B, int32_t C, int32_t C_real, int32_t S,
                                 float* dpre2, float* dpre1, float* gpool, float* dw1, float* db1, float* dw2,
                                 float* db2, void* stream) {
-  NBDT_REQUIRE(dgate && gate && pre1 && pooled && w1 && w2 && dpre2 && dpre1 && gpool && dw1 && db1 && dw2 && db2,
-               "null argument");
+  NBDT_REQUIRE(dgate && gate && pre1 && pooled && w1 && w2 && dpre2 && dpre1 && gpool, "null argument");
+  NBDT_REQUIRE((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2), "parameter gradients: all four or none");
   NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(C_real > 256 ? 1024 : 256),
                      (size_t)(C_real + S + (C_real > 256 ? 16 : 4) * S) * sizeof(float), st, dgate, gate, pre1, w1, w2, C, C_real, S, dpre2, dpre1,
                      gpool);
   NBDT_LAUNCH_CHECK();
+  if (!dw1) return NBDT_OK;        // data part only: the caller runs nbdt_se_param_grad where it likes (another stream)
+  return nbdt_se_param_grad(dpre2, dpre1, pre1, pooled, B, C, C_real, S, dw1, db1, dw2, db2, stream);
+}
+
+extern "C" int nbdt_se_param_grad(const float* dpre2, const float* dpre1, const float* pre1, const float* pooled,
+                                  int32_t B, int32_t C, int32_t C_real, int32_t S, float* dw1, float* db1, float* dw2,
+                                  float* db2, void* stream) {
+  NBDT_REQUIRE(dpre2 && dpre1 && pre1 && pooled && dw1 && db1 && dw2 && db2, "null argument");
+  NBDT_REQUIRE(B > 0 && C_real > 0 && C_real <= C && S > 0 && S <= 256, "bad SE sizes");
+  hipStream_t st = (hipStream_t)stream;
   const int n = C_real * S;
   const int bchunk = deterministic() ? B : 16;     // (one chunk: one add per address)
   hipLaunchKernelGGL(se_param_grad_kernel, dim3((n + 255) / 256, (B + bchunk - 1) / bchunk), dim3(256), 0, st, dpre2,

@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(block_of(TPS)) void node_outputs_kernel(TreeView t,
 // host side
 
 extern "C" const char* nbdt_last_error(void) { return nbdt::g_err; }
-extern "C" int nbdt_version(void) { return 107; }     // 107: nbdt_bn_act_se_sums / _se_bwd_apply; 106: nbdt_conv_desc.ksplit is live (was reserved), nbdt_conv_seg_*
+extern "C" int nbdt_version(void) { return 108; }     // 108: nbdt_se_param_grad, nbdt_se_gate_bwd without parameter gradients; 107: nbdt_bn_act_se_sums / _se_bwd_apply; 106: nbdt_conv_desc.ksplit is live (was reserved), nbdt_conv_seg_*
 extern "C" int nbdt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

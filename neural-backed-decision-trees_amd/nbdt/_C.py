@@ -176,6 +176,7 @@ SIGNATURES = {
     "nbdt_se_gate_fwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "nbdt_se_gate_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P,
                                  _P, _P, _P]),
+    "nbdt_se_param_grad": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "nbdt_dropout_fwd": (c_int, [_P, c_int64, c_float, ctypes.c_uint32, _P, _P, _P]),
     "nbdt_dropout_bwd": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "nbdt_linear_fwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),

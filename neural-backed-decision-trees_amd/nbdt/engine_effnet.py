@@ -54,14 +54,20 @@ class DepthwiseConv:
     def backward_data(self, gy, gx):
         ops.dwconv_bwd_data(gy, self.store.p(self.name), gx, self.k, self.stride)
 
-    def backward_weight(self, x, gy):
+    def backward_weight(self, x, gy, also=None):
+        """also: a further launch that only feeds the optimizer (the SE block's parameter gradients), issued behind the
+        weight gradient on the same stream -- one cross-stream dependency for both."""
         side = getattr(self, "side_stream", None)
         if side is None:
             ops.dwconv_bwd_weight(x, gy, self.store.g(self.name), self.k, self.stride)
+            if also is not None:
+                also()
             return
         side.wait_stream(torch.cuda.current_stream(x.device))     # second stream: see WRNEngine
         with torch.cuda.stream(side):
             ops.dwconv_bwd_weight(x, gy, self.store.g(self.name), self.k, self.stride)
+            if also is not None:
+                also()
 
 
 class SqueezeExcite:
@@ -90,11 +96,17 @@ class SqueezeExcite:
         ops.se_gate_fwd(pooled, p(self.name + ".conv1.weight"), p(self.name + ".conv1.bias"),
                         p(self.name + ".conv2.weight"), p(self.name + ".conv2.bias"), pre1, gate, self.c_real)
 
-    def backward(self, dgate, gate, pre1, pooled, dpre2, dpre1, gpool):
+    def backward(self, dgate, gate, pre1, pooled, dpre2, dpre1, gpool, defer_params=False):
+        """defer_params: the data part only; returns the launch of the parameter gradients for the caller to place (they
+        read dpre2 / dpre1 / pre1 / pooled and feed nothing but the optimizer)."""
         p, g = self.store.p, self.store.g
+        grads = (g(self.name + ".conv1.weight"), g(self.name + ".conv1.bias"), g(self.name + ".conv2.weight"),
+                 g(self.name + ".conv2.bias"))
         ops.se_gate_bwd(dgate, gate, pre1, pooled, p(self.name + ".conv1.weight"), p(self.name + ".conv2.weight"),
-                        dpre2, dpre1, gpool, g(self.name + ".conv1.weight"), g(self.name + ".conv1.bias"),
-                        g(self.name + ".conv2.weight"), g(self.name + ".conv2.bias"), self.c_real)
+                        dpre2, dpre1, gpool, *((None,) * 4 if defer_params else grads), self.c_real)
+        if defer_params:
+            return lambda: ops.se_param_grad(dpre2, dpre1, pre1, pooled, *grads, self.c_real)
+        return None
 
 
 class EfficientNetEngine(_Engine):
@@ -145,6 +157,7 @@ class EfficientNetEngine(_Engine):
         self.finalize()
         self._step = 0
         self.dropout_seed = seed
+        self.defer_se_params = True   # SE parameter gradients behind the depthwise weight gradient on the second stream
         self.fuse_se_bwd = True   # SE backward: dL/dgate and bn2's backward sums from ONE pass over (gd, d_raw)
         self._side = side_stream(self.device)     # weight gradients on the process's second stream (see WRNEngine)
         for c in self.convs + self.dws:
@@ -367,9 +380,12 @@ class EfficientNetEngine(_Engine):
             else:
                 dgate = self._vec(f"dgate{tag}", B, mid)
                 ops.bn_act_pool(d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, dgate, act=ACT, mul=gd, scale=1.0)
-            u["se"].backward(dgate, gate, self._vec(k + ".pre1", B, u["se"].mid),
-                             self._vec(k + ".pooled", B, mid), self._vec("dpre2", B, mid),
-                             self._vec("dpre1", B, u["se"].mid), gpool)
+            # the SE block's parameter gradients go behind the depthwise weight gradient on the second stream (their
+            # workspaces alternate between consecutive units like the gradient buffers)
+            se_params = u["se"].backward(dgate, gate, self._vec(k + ".pre1", B, u["se"].mid),
+                                         self._vec(k + ".pooled", B, mid), self._vec(f"dpre2_{par}{tag}", B, mid),
+                                         self._vec(f"dpre1_{par}{tag}", B, u["se"].mid), gpool,
+                                         defer_params=self.defer_se_params)
             if one_pass:
                 ops.bn_act_se_bwd_apply(gd, gate, gpool, sums, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, bn.dsum,
                                         st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT)
@@ -381,7 +397,7 @@ class EfficientNetEngine(_Engine):
                 e_raw = self.buf(k + ".e_raw", B, hi, wi, mid)
                 e_act = self.buf(k + ".e_act", B, hi, wi, mid)
                 ge = self.buf(f"ge_{mid}_{hi}_{par}{tag}", B, hi, wi, mid)
-                u["dw"].backward_weight(e_act, gd)
+                u["dw"].backward_weight(e_act, gd, also=se_params)
                 bn = u["bn1"]
                 if u["dw"].stride == 1 and self.fuse_dw_bn_bwd:
                     # the depthwise data gradient's epilogue leaves bn1's backward sums in the slots: no reduction
@@ -405,7 +421,7 @@ class EfficientNetEngine(_Engine):
                     u["conv1"].backward_data(ge, g_in)
             else:
                 g_in = self.buf(f"g_{cin}_{hi}{tag}", B, hi, wi, cin)
-                u["dw"].backward_weight(x_in, gd)
+                u["dw"].backward_weight(x_in, gd, also=se_params)
                 u["dw"].backward_data(gd, g_in)
             u["dbg"] = {"g_out": g, "g_in": g_in, "gp": gp, "gd": gd}
             g, h, w = g_in, hi, wi

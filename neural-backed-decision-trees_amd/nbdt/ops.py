@@ -706,10 +706,17 @@ def se_gate_fwd(pooled, w1, b1, w2, b2, pre1, gate, c_real):
 
 
 def se_gate_bwd(dgate, gate, pre1, pooled, w1, w2, dpre2, dpre1, gpool, dw1, db1, dw2, db2, c_real):
+    """dw1 = db1 = dw2 = db2 = None: the data part only (follow with se_param_grad, on any stream ordered after this)."""
     B, C = pooled.shape
     check(lib().nbdt_se_gate_bwd(ptr(dgate), ptr(gate), ptr(pre1), ptr(pooled), ptr(w1), ptr(w2), B, C, c_real,
                                  w1.shape[0], ptr(dpre2), ptr(dpre1), ptr(gpool), ptr(dw1), ptr(db1), ptr(dw2),
                                  ptr(db2), stream_ptr(pooled.device)))
+
+
+def se_param_grad(dpre2, dpre1, pre1, pooled, dw1, db1, dw2, db2, c_real):
+    B, C = pooled.shape
+    check(lib().nbdt_se_param_grad(ptr(dpre2), ptr(dpre1), ptr(pre1), ptr(pooled), B, C, c_real, dw1.shape[0],
+                                   ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), stream_ptr(pooled.device)))
 
 
 def dropout_fwd(x, p, seed, mask, y):

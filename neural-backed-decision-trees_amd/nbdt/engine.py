@@ -1236,6 +1236,8 @@ class ResNetEngine(_Engine):
         self._side = side_stream(self.device)     # weight gradients on a second stream (see WRNEngine)
         for c in self.convs:
             c.side_stream = self._side
+        # (GB/s per CU, time budget of bn1's confined pass at 128 images in us, min CUs, max CUs) or None: see backward()
+        self.res_share = (47.0, 15.0, 16, 128)
         dev = self.device
         # identity "BN" for the plain average-pool head (features are already post-ReLU)
         self._id_mean = torch.zeros(cin, device=dev)
@@ -1374,13 +1376,27 @@ class ResNetEngine(_Engine):
             else:
                 # identity shortcut: the masked gradient IS part of the block-input gradient
                 blk["bn2"].backward(g, out, t2, gt2, relu=True, g_resid=g_in)
-            blk["conv2"].backward_weight(a1, gt2)
-            if self.fuse_bn1_bwd and self.act_dtype == torch.bfloat16:
+            share = (self.res_share is not None and (two_streams or self.debug_share_serial) and self.fuse_bn1_bwd
+                     and self.act_dtype == torch.bfloat16 and ops.cu_topology_is_mi355x(self.device))
+            if share:
+                # CU sharing as in WRNEngine (fused-sums form): conv2's weight gradient is issued AFTER its data gradient,
+                # sized for 256 - n CUs, and bn1's elementwise pass that follows on this stream is confined to n CUs --
+                # in the plain order the pass's blocks waited for the weight gradient's to leave their CUs
+                # (bn_bwd_fold_partials: 42 us in the trace for 5 us of work, profiles/r06_c4_step_dump_before.txt)
+                gbps, us, lo, hi_cus = self.res_share
+                blk["conv2"].backward_data(gt2, ga1, bn=blk["bn1"], bn_x=t1, partials=self.partials(t1))
+                budget, n1 = ops.plan_cu_share(blk["conv2"].plan(B, ho, wo)[3], B * ho * wo * cout, 3, gbps,
+                                               us * B / 128.0, lo, hi_cus)
+                blk["conv2"].backward_weight(a1, gt2, cu_budget=budget)
+                blk["bn1"].backward_fused(ga1, t1, gt1, self.partials(t1), cus=n1)
+            elif self.fuse_bn1_bwd and self.act_dtype == torch.bfloat16:
                 # conv2's data gradient is dL/d(relu(bn1(t1))): its epilogue also emits bn1's backward sums (as in
                 # WRNEngine's fused order), so ga1 is not re-read for them -- one HBM-bound pass fewer per block
+                blk["conv2"].backward_weight(a1, gt2)
                 blk["conv2"].backward_data(gt2, ga1, bn=blk["bn1"], bn_x=t1, partials=self.partials(t1))
                 blk["bn1"].backward_fused(ga1, t1, gt1, self.partials(t1))
             else:
+                blk["conv2"].backward_weight(a1, gt2)
                 blk["conv2"].backward_data(gt2, ga1)
                 blk["bn1"].backward(ga1, None, t1, gt1, relu=True)
             blk["conv1"].backward_weight(x_in, gt1)

@@ -796,6 +796,7 @@ def test_resnet_two_stream_backward_equals_the_serial_one_bit_for_bit(determinis
         one = E.ResNetEngine(num_classes=classes, device=DEV, seed=9)
         one.debug_keep = True
         one.set_overlap(False)
+        one.debug_share_serial = True      # the CU-sharing schedule's launches (budgets = summation splits, CU counts) on one stream
         z2, l2, g2 = _one_backward(two, crit, x, y)
         z2b, l2b, g2b = _one_backward(two, crit, x, y)
         z1, l1, g1 = _one_backward(one, crit, x, y)

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void mb_se_finalize_kernel(float* __restrict__
   const size_t plane = (size_t)B * C;
   float s0 = 0.f, s1 = 0.f;
   if (c < C)
+#pragma unroll 4
     for (int b = lane; b < B; b += 4) {
       const size_t o = (size_t)b * C + c;
       const float gt = gate[o], gp = gpool[o] * inv_hw;
@@ -781,6 +782,7 @@ __global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float* __restri
   __syncthreads();
   for (int s = wave; s < S; s += nwave) {
     float acc = 0.f;
+#pragma unroll 8
     for (int c = lane; c < Cr; c += 64) acc += w1[(size_t)s * Cr + c] * pl[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -797,6 +799,7 @@ __global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float* __restri
     float v = 0.f;
     if (c < Cr) {
       float acc = b2[c];
+#pragma unroll 8
       for (int s = 0; s < S; ++s) acc += w2[(size_t)c * S + s] * hl[s];
       v = sigmoidf_(acc);
     }
@@ -833,8 +836,10 @@ __global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restri
     for (int s0 = 0; s0 < S; s0 += 64) {
       const int s2 = s0 + lane;
       float acc = 0.f;
-      if (s2 < S)
+      if (s2 < S) {
+#pragma unroll 8
         for (int c = wave; c < Cr; c += nwave) acc += w2[(size_t)c * S + s2] * d2[c];
+      }
       if (s2 < S) part[wave * S + s2] = acc;
     }
     __syncthreads();
@@ -844,6 +849,7 @@ __global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restri
     if (nwave > 4) {
       for (int wv = 0; wv < nwave; ++wv) acc += part[wv * S + s];
     } else {
+#pragma unroll 8
       for (int c = lane; c < Cr; c += 64) acc += w2[(size_t)c * S + s] * d2[c];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -858,8 +864,10 @@ __global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restri
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += nthr) {
     float acc = 0.f;
-    if (c < Cr)
+    if (c < Cr) {
+#pragma unroll 8
       for (int s = 0; s < S; ++s) acc += w1[(size_t)s * Cr + c] * d1[s];
+    }
     gpool[(size_t)b * C + c] = acc;
   }
 }

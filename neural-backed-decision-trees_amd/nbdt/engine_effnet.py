@@ -197,7 +197,8 @@ class EfficientNetEngine(_Engine):
         the unit's input, expanded (before the depthwise conv), depthwise-output and output tensors:
           forward   expand conv X + E | BatchNorm + swish 2E | depthwise E + D | squeeze D | scale 2D | project D + O |
                     BatchNorm (+ skip) 2O (+ X)
-          backward  bn3 5O | project weight gradient D + O, data gradient O + D | dL/dgate 2D | bn2 + SE 5D | depthwise
+          backward  bn3 5O | project weight gradient D + O, data gradient O + D | dL/dgate + bn2's sums 2D (one pass since round
+                    6; fuse_se_bwd off: 2D + 2D) | bn2 + SE elementwise 3D | depthwise
                     weight gradient E + D, data gradient + bn1 sums D + 2E | bn1 elementwise 3E | expand weight gradient
                     X + E, data gradient E + X (+ X when it accumulates onto the skip gradient)"""
         h = w = size // 2
@@ -205,6 +206,7 @@ class EfficientNetEngine(_Engine):
         stem = e(h, w, self.stem_c)
         total = 12 * B * size * size + 2 * stem + 2 * stem      # image in, stem conv out, BatchNorm + swish (read + write)
         total += 5 * stem + 12 * B * size * size + stem         # backward of that BatchNorm, stem weight gradient
+        se = 2 if self.fuse_se_bwd else 4                      # tensor reads of the reduction pass(es) over (gd, d_raw)
         for u in self.units:
             s = u["stride"]
             ho, wo = h // s, w // s
@@ -213,10 +215,10 @@ class EfficientNetEngine(_Engine):
             res = X if u["residual"] else 0
             if u["conv1"] is not None:
                 fwd = (X + E) + 2 * E + (E + D) + D + 2 * D + (D + O) + 2 * O + res
-                bwd = 5 * O + (D + O) + (O + D) + 2 * D + 5 * D + (E + D) + (D + 2 * E) + 3 * E + (X + E) + (E + X) + res
+                bwd = 5 * O + (D + O) + (O + D) + se * D + 3 * D + (E + D) + (D + 2 * E) + 3 * E + (X + E) + (E + X) + res
             else:       # stage 1: depthwise on the unit's input, no expand conv
                 fwd = (X + D) + D + 2 * D + (D + O) + 2 * O + res
-                bwd = 5 * O + (D + O) + (O + D) + 2 * D + 5 * D + (X + D) + (D + X)
+                bwd = 5 * O + (D + O) + (O + D) + se * D + 3 * D + (X + D) + (D + X)
             total += fwd + bwd
             h, w = ho, wo
         F, L = e(h, w, self.feat_c), e(h, w, self.units[-1]["cout"])

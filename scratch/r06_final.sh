@@ -2,7 +2,7 @@
 # Round 6, final evidence run: full GPU suite, smoke, the driver's bench command, rocprofv3 passes of the final state
 # (kernel stats one / two streams, FETCH / WRITE, SQ counters), the step timeline, the other configurations' profiles.
 cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r06_final
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${R06_OUT:-r06_final}
 mkdir -p $OUT
 if [ "$1" != "noprof" ]; then
 ( time timeout 1500 python -m pytest tests -m gpu -q --durations=5 ) > $OUT/pytest.log 2>&1

@@ -24,23 +24,8 @@ for C in c1 c3 c4 c4inf c5; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr_$C -o t -- python $R/scratch/run_config.py $C --steps 5 --warmup 2 --one-stream > $OUT/tr_$C.log 2>&1
   python $R/scratch/kernel_stats_report.py $(find $OUT/tr_$C -name "*kernel_stats.csv" | head -1) 7 $OUT/${C}_kernel_stats_one_stream.txt "$C, one stream, 7 steps profiled (2 warm-up + 5)" > /dev/null
 done
-# EfficientNet-B0 (config 5): HBM-side bytes of one training step
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c5_fetch -o t -- python $R/scratch/run_config.py c5 --steps 1 --warmup 1 --one-stream > $OUT/c5_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c5_write -o t -- python $R/scratch/run_config.py c5 --steps 1 --warmup 1 --one-stream > $OUT/c5_write.log 2>&1
-python - <<PY
-import csv, glob
-def tot(d, name):
-    s = 0.0
-    for p in glob.glob(f"$OUT/{d}/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(p)):
-            if r["Counter_Name"] == name: s += float(r["Counter_Value"])
-    return s * 1024.0
-f, w = tot("c5_fetch", "FETCH_SIZE"), tot("c5_write", "WRITE_SIZE")
-open("$OUT/c5_hbm_traffic.txt", "w").write(
-    "# EfficientNet-B0 / Imagenet1000 224x224, batch 128: HBM-side bytes of TWO training steps (1 warm-up + 1), one stream,\n"
-    "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB as reported; FETCH x2 = gfx950 correction)\n"
-    f"FETCH_SIZE {f/1e9:.2f} GB raw, {2*f/1e9:.2f} GB corrected; WRITE_SIZE {w/1e9:.2f} GB; per step {(2*f+w)/2e9:.2f} GB\n")
-print(open("$OUT/c5_hbm_traffic.txt").read())
-PY
+# EfficientNet-B0 (config 5): HBM-side bytes of one training step, by kernel family (the LAST of two steps: the first one
+# zero-fills every buffer it allocates, +3 GB of writes)
+bash $R/scratch/c5_traffic_by_kernel.sh ${R06_OUT:-r06_final} > /dev/null 2>&1; head -4 $OUT/c5_traffic_by_kernel.txt
 find $OUT $P -name "*kernel_trace.csv" -delete; find $OUT $P -name "*counter_collection.csv" -size +20M -delete
 du -sh $OUT $P

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
   }
 }
 
-template <bool RELU, bool HAS_RES>
+template <bool RELU, bool HAS_RES, bool NT>
 __global__ __launch_bounds__(kMaxThreads) void bn_apply_kernel(const bf16_t* __restrict__ x,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ rstd,
@@ -158,9 +158,9 @@ __global__ __launch_bounds__(kMaxThreads) void bn_apply_kernel(const bf16_t* __r
   for (int p = blockIdx.x * PY + py; p < g.npix; p += gridDim.x * PY) {
     const int o = pad_offset(g, p) + cx * 8;
     float f[8];
-    unpack8(*(const u32x4_t*)(x + o), f);
+    unpack8(ld16_stream<NT>(x + o), f);
     float r[8];
-    if (HAS_RES) unpack8(*(const u32x4_t*)(res + o), r);
+    if (HAS_RES) unpack8(ld16_stream<NT>(res + o), r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float v = f[i] * sc[i] + sh[i];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kMaxThreads) void bn_bwd_apply_kernel(
 #define NBDT_CUS_IN_FLIGHT 2   // 4 measured equal, 8 slower (profiles/r06_session2_small_abs.txt)
 #endif
 constexpr int kCusInFlight = NBDT_CUS_IN_FLIGHT;   // pixels (16-byte loads per tensor) in flight per thread of the confined passes
-template <bool HAS_ADD, bool FOLD>
+template <bool HAS_ADD, bool FOLD, bool NT>
 __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
     const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -411,19 +411,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
     for (int u = 0; u < kCusInFlight; ++u) o[u] = pad_offset(g, p + u * step) + cx * 8;
 #pragma unroll
     for (int u = 0; u < kCusInFlight; ++u) {
-      vx[u] = *(const u32x4_t*)(x + o[u]);
-      vg[u] = *(const u32x4_t*)(gy + o[u]);
+      vx[u] = ld16_stream<NT>(x + o[u]);
+      vg[u] = ld16_stream<NT>(gy + o[u]);
       va[u] = vx[u];
-      if (HAS_ADD) va[u] = *(const u32x4_t*)(gx_add + o[u]);
+      if (HAS_ADD) va[u] = ld16_stream<NT>(gx_add + o[u]);
     }
 #pragma unroll
     for (int u = 0; u < kCusInFlight; ++u) one(vx[u], vg[u], va[u], o[u]);
   }
   for (; p < g.npix; p += step) {
     const int o0 = pad_offset(g, p) + cx * 8;
-    const u32x4_t x0 = *(const u32x4_t*)(x + o0), g0 = *(const u32x4_t*)(gy + o0);
+    const u32x4_t x0 = ld16_stream<NT>(x + o0), g0 = ld16_stream<NT>(gy + o0);
     u32x4_t a0 = x0;
-    if (HAS_ADD) a0 = *(const u32x4_t*)(gx_add + o0);
+    if (HAS_ADD) a0 = ld16_stream<NT>(gx_add + o0);
     one(x0, g0, a0, o0);
   }
 }
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_cus_kernel(
 // With it the BatchNorm-backward sums no longer have to come out of the data gradient's epilogue, which reads the
 // BatchNorm input in an HBM burst while the matrix pipes wait (+50 us per launch at 32x32x160): the whole
 // BatchNorm backward (reduce, fold, apply) becomes HBM-bound work beside the weight gradient.
+template <bool NT>
 __global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* __restrict__ gy,
                                                                  const bf16_t* __restrict__ x,
                                                                  const float* __restrict__ mean,
@@ -477,15 +478,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_cus_kernel(const bf16_t* _
 #pragma unroll
       for (int u = 0; u < kCusInFlight; ++u) {
         const int o = pad_offset(g, p + u * step) + cx * 8;
-        vx[u] = *(const u32x4_t*)(x + o);
-        vg[u] = *(const u32x4_t*)(gy + o);
+        vx[u] = ld16_stream<NT>(x + o);
+        vg[u] = ld16_stream<NT>(gy + o);
       }
 #pragma unroll
       for (int u = 0; u < kCusInFlight; ++u) one(vx[u], vg[u]);
     }
     for (; p < g.npix; p += step) {
       const int o0 = pad_offset(g, p) + cx * 8;
-      one(*(const u32x4_t*)(x + o0), *(const u32x4_t*)(gy + o0));
+      one(ld16_stream<NT>(x + o0), ld16_stream<NT>(gy + o0));
     }
   }
   // block fold: [PY][c8][16] floats in LDS, then one atomic per (channel, sum) of the block into its slot
@@ -732,9 +733,14 @@ extern "C" int nbdt_bn_apply(const void* x, const float* save_mean, const float*
   const PadGeom g = make_geom(B, H, W, C);
   const Layout l = layout_for(C);
   const dim3 grid(grid_for(g, l, 8)), blk(l.threads);
+  const bool nt = stream_nt((long long)B * g.img * 2);      // (nontemporal loads: tensors that cannot stay in the Infinity Cache)
 #define NBDT_APPLY(R, S)                                                                                         \
-  hipLaunchKernelGGL((bn_apply_kernel<R, S>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, \
-                     beta, (const bf16_t*)residual, g, l.c8, l.py, (bf16_t*)y)
+  do {                                                                                                           \
+    if (nt) hipLaunchKernelGGL((bn_apply_kernel<R, S, true>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, \
+                               beta, (const bf16_t*)residual, g, l.c8, l.py, (bf16_t*)y);                          \
+    else hipLaunchKernelGGL((bn_apply_kernel<R, S, false>), grid, blk, 0, st, (const bf16_t*)x, save_mean, save_rstd, gamma, \
+                            beta, (const bf16_t*)residual, g, l.c8, l.py, (bf16_t*)y);                             \
+  } while (0)
   if (relu) { if (residual) NBDT_APPLY(true, true); else NBDT_APPLY(true, false); }
   else { if (residual) NBDT_APPLY(false, true); else NBDT_APPLY(false, false); }
 #undef NBDT_APPLY
@@ -875,12 +881,17 @@ extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float*
   const PadGeom g = make_geom(B, H, W, C);
   const int c8 = C / 8;
   const int py = 1024 / c8;                       // C <= 2048 (check_shape): at least 4 pixel rows
+  const bool nt = stream_nt((long long)B * g.img * 2);
   constexpr int kForceLds = 96 * 1024;            // more than half a CU's LDS: one block per CU
   static DeviceAttr site;
   if (site.need(kForceLds)) {
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, false>),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, false, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, false>),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, false, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, false, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
     site.done(kForceLds);
   }
@@ -889,13 +900,19 @@ extern "C" int nbdt_bn_bwd_apply_cus(const void* gy, const void* x, const float*
   if (blocks > max_blocks) blocks = max_blocks;
   const dim3 grid(blocks), blk(1024);
   if (gx_add)
-    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, false>), grid, blk, kForceLds, (hipStream_t)stream,
+    { if (nt) hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, false, true>), grid, blk, kForceLds, (hipStream_t)stream,
                        (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum,
                        (const bf16_t*)gx_add, g, c8, py, (bf16_t*)gx, nullptr, nullptr, nullptr, nullptr, nullptr);
+      else hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, false, false>), grid, blk, kForceLds, (hipStream_t)stream,
+                       (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum,
+                       (const bf16_t*)gx_add, g, c8, py, (bf16_t*)gx, nullptr, nullptr, nullptr, nullptr, nullptr); }
   else
-    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, false>), grid, blk, kForceLds, (hipStream_t)stream,
+    { if (nt) hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, false, true>), grid, blk, kForceLds, (hipStream_t)stream,
                        (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, nullptr, g, c8, py,
                        (bf16_t*)gx, nullptr, nullptr, nullptr, nullptr, nullptr);
+      else hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, false, false>), grid, blk, kForceLds, (hipStream_t)stream,
+                       (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, dsum, nullptr, g, c8, py,
+                       (bf16_t*)gx, nullptr, nullptr, nullptr, nullptr, nullptr); }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }
@@ -912,10 +929,13 @@ extern "C" int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float
   const PadGeom g = make_geom(B, H, W, C);
   const int c8 = C / 8;
   const int py = 1024 / c8;
+  const bool nt = stream_nt((long long)B * g.img * 2);
   constexpr int kForceLds = 96 * 1024;            // one block per CU; the block fold uses py*c8*64 <= 64 KB of it
   static DeviceAttr site;
   if (site.need(kForceLds)) {
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
     site.done(kForceLds);
   }
@@ -925,8 +945,10 @@ extern "C" int nbdt_bn_bwd_reduce_cus(const void* gy, const void* x, const float
   SlotTarget t;
   rc = slot_target(st, scratch, blocks, 2 * (size_t)C, &t);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_reduce_cus_kernel, dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+  { if (nt) hipLaunchKernelGGL((bn_bwd_reduce_cus_kernel<true>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
                      (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, t.ptr, t.mask);
+    else hipLaunchKernelGGL((bn_bwd_reduce_cus_kernel<false>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, t.ptr, t.mask); }
   NBDT_LAUNCH_CHECK();
   rc = slot_finish(st, t, blocks, 2 * (size_t)C, scratch);
   if (rc) return rc;
@@ -948,14 +970,21 @@ extern "C" int nbdt_bn_bwd_cus(const void* gy, const void* x, const float* save_
   const PadGeom g = make_geom(B, H, W, C);
   const int c8 = C / 8;
   const int py = 1024 / c8;
+  const bool nt = stream_nt((long long)B * g.img * 2);
   constexpr int kForceLds = 96 * 1024;
   static DeviceAttr site;
   if (site.need(kForceLds)) {
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, true>),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_reduce_cus_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
-    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, true>),
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, true, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<true, true, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, true, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
+    NBDT_ATTR_CHECK(site, hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_bwd_apply_cus_kernel<false, true, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kForceLds));
     site.done(kForceLds);
   }
@@ -965,19 +994,27 @@ extern "C" int nbdt_bn_bwd_cus(const void* gy, const void* x, const float* save_
   SlotTarget t;
   rc = slot_target(st, slots, blocks, 2 * (size_t)C, &t);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_reduce_cus_kernel, dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+  { if (nt) hipLaunchKernelGGL((bn_bwd_reduce_cus_kernel<true>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
                      (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, t.ptr, t.mask);
+    else hipLaunchKernelGGL((bn_bwd_reduce_cus_kernel<false>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+                     (const bf16_t*)x, save_mean, save_rstd, gamma, beta, g, c8, py, t.ptr, t.mask); }
   NBDT_LAUNCH_CHECK();
   rc = slot_finish(st, t, blocks, 2 * (size_t)C, slots);      // (deterministic mode: the block rows -> slot 0)
   if (rc) return rc;
   if (gx_add)
-    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, true>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+    { if (nt) hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, true, true>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
                        (const bf16_t*)x, save_mean, save_rstd, gamma, beta, nullptr, (const bf16_t*)gx_add, g, c8, py,
                        (bf16_t*)gx, slots, slots_other, dsum, dgamma, dbeta);
+      else hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<true, true, false>), dim3(blocks), dim3(1024), kForceLds, st, (const bf16_t*)gy,
+                       (const bf16_t*)x, save_mean, save_rstd, gamma, beta, nullptr, (const bf16_t*)gx_add, g, c8, py,
+                       (bf16_t*)gx, slots, slots_other, dsum, dgamma, dbeta); }
   else
-    hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, true>), dim3(blocks), dim3(1024), kForceLds, st,
+    { if (nt) hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, true, true>), dim3(blocks), dim3(1024), kForceLds, st,
                        (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, nullptr, nullptr, g, c8, py,
                        (bf16_t*)gx, slots, slots_other, dsum, dgamma, dbeta);
+      else hipLaunchKernelGGL((bn_bwd_apply_cus_kernel<false, true, false>), dim3(blocks), dim3(1024), kForceLds, st,
+                       (const bf16_t*)gy, (const bf16_t*)x, save_mean, save_rstd, gamma, beta, nullptr, nullptr, g, c8, py,
+                       (bf16_t*)gx, slots, slots_other, dsum, dgamma, dbeta); }
   NBDT_LAUNCH_CHECK();
   return NBDT_OK;
 }

@@ -20,7 +20,7 @@
     (defined(NBDT_WPP_NO_EPI) || defined(NBDT_WKS_NO_EXCHANGE) || defined(NBDT_WKS_DMA_IN_M) || defined(NBDT_WPP_MIN_STAGES) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
      defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) || defined(NBDT_PP_NO_PAD) ||                    \
      defined(NBDT_HALO_NO_ACCUMULATE) || defined(NBDT_DW_TARGET) || defined(NBDT_DW_U) || defined(NBDT_HEAD_SPB) ||    \
-     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) || defined(NBDT_NO_XCD_CONTIGUOUS) || defined(NBDT_CUS_IN_FLIGHT) ||                      \
+     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) || defined(NBDT_NO_XCD_CONTIGUOUS) || defined(NBDT_CUS_IN_FLIGHT) || defined(NBDT_NT_MIN_MB) ||                      \
      (defined(NBDT_HEAD_SKIP) && (NBDT_HEAD_SKIP + 0) != 0) || (defined(NBDT_PP_ABLATE) && (NBDT_PP_ABLATE + 0) != 0) || \
      (defined(NBDT_PP_SCHED) && (NBDT_PP_SCHED + 0) != 0) || (defined(NBDT_PP_TIMING) && (NBDT_PP_TIMING + 0) != 0) ||  \
      (defined(NBDT_WPP_TIMING) && (NBDT_WPP_TIMING + 0) != 0) || (defined(NBDT_SEG_TIMING) && (NBDT_SEG_TIMING + 0) != 0) || (defined(NBDT_RULES_TIMING) && (NBDT_RULES_TIMING + 0) != 0))
@@ -251,6 +251,23 @@ __device__ __forceinline__ void glds16_sf(const void* sbase, unsigned voff, unsi
 namespace nbdt {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// 16-byte load of an operand that is STREAMED -- read once by this launch, not again soon: the elementwise / reduction
+// passes over activation and gradient tensors.  NT: nontemporal, so the stream does not push what the MFMA kernels re-read
+// (weight tiles, halo rows) out of the L2s and the Infinity Cache.  A compile-time choice (a run-time select between the two
+// load forms measured like plain loads), made per launch by stream_nt(): only tensors too large to stay in the 256 MB cache
+// anyway.  WRN-28-10 at 512 images (189 / 106 MB tensors): 16.37 -> 16.23 ms per step; ResNet18 at 128 x 64 x 64 (<= 71 MB)
+// and EfficientNet-B0 LOSE 0.4 / 2 % with nontemporal loads -- their consumers find the producers' tensors in the cache
+// (profiles/r06_nt_loads_ab.txt).  Nontemporal STORES measured slower and are not used.
+template <bool NT>
+__device__ __forceinline__ u32x4_t ld16_stream(const void* p) {
+  if (NT) return __builtin_nontemporal_load((const u32x4_t*)p);
+  return *(const u32x4_t*)p;
+}
+#ifndef NBDT_NT_MIN_MB
+#define NBDT_NT_MIN_MB 96
+#endif
+inline bool stream_nt(long long tensor_bytes) { return tensor_bytes >= ((long long)NBDT_NT_MIN_MB << 20); }
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
 #pragma unroll

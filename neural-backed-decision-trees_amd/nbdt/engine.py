@@ -873,11 +873,12 @@ class WRNEngine(_Engine):
         # BatchNorm-backward passes beside the weight gradients on disjoint CUs: on by default, kept only if the
         # calibration before the first backward() finds it faster on this box (set_cu_share(None) turns it off)
         self.set_cu_share(47.0)
-        # per stage (output-grid pixels -> split_target_us): the 32x32 and 16x16 stages are bound by the main stream's
-        # chain (data gradient, then the confined reduce + apply: 290-310 / 225 us against weight gradients of 250-300 / 203),
-        # so their passes get more CUs than one number for all stages gives them: 104 / 120 instead of 96 / 112 beside
-        # the stage-1 weight gradients, 72 instead of 56 in stage 2 (profiles/r06_stage_target_ab.txt: 15.92 -> 15.83 ms)
-        self.share_stage_us = {1024: 170.0, 256: 150.0}
+        # per stage (output-grid pixels -> split_target_us, quoted at 512 images): the 32x32 and 16x16 stages are bound by the
+        # main stream's chain (data gradient, then the confined reduce + apply), the 8x8 stage by its MFMA work.  With plain
+        # loads in the passes the chain-bound stages wanted more CUs (170 / 150 us: 104-120 / 72); with the nontemporal loads
+        # of round 6 the passes are faster and 190 / 170 us (96-112 / 56-72 CUs) is best again -- the value of the per-stage
+        # table is now the batch scaling (_split_us) and a place to retune (profiles/r06_stage_target_ab.txt, sections 1-5)
+        self.share_stage_us = {1024: 190.0, 256: 170.0}
 
     # ---- the shape-changing units on the slice-list kernel (csrc/conv_seg.hip)
     def _seg_conv1(self, u, B, h, w):

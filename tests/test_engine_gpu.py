@@ -366,8 +366,8 @@ def test_bench_configuration_step_matches_fp32_oracle(schedule, bench_config_ora
         # units, beside their space-to-depth weight gradients; their weight gradients CU-budgeted
         assert log["igemm_bnbwd"] == 0 and len(log["bn_bwd_cus"]) == 23
         assert all(n % 8 == 0 and 16 <= n <= 128 for n in log["bn_bwd_cus"]), log["bn_bwd_cus"]
-        assert {104, 120} <= set(log["bn_bwd_cus"])           # the stage-1 plans of the benched configuration
-        assert 72 in log["bn_bwd_cus"]                        # (engine.share_stage_us: 170 us at 32x32, 150 at 16x16)
+        assert {96, 112} <= set(log["bn_bwd_cus"])            # the stage-1 plans of the benched configuration
+        assert {56, 72} <= set(log["bn_bwd_cus"])             # (engine.share_stage_us: 190 us at 32x32, 170 at 16x16)
         assert sum(b > 0 for b in log["wgrad_budgets"]) == 23
         # (the last implicit GEMM of backward: the first unit's conv1 + shortcut data gradient, one slice-list launch)
         assert ops.last_igemm_kernel() == "conv_seg_kernel"

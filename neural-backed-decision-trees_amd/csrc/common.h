@@ -20,7 +20,7 @@
     (defined(NBDT_WPP_NO_EPI) || defined(NBDT_WKS_NO_EXCHANGE) || defined(NBDT_WKS_DMA_IN_M) || defined(NBDT_WPP_MIN_STAGES) || defined(NBDT_WPP_FRAC8) || defined(NBDT_PP_KFRAC5) ||    \
      defined(NBDT_DMA_WTILED_FAKE) || defined(NBDT_PP_DUMMY_VALU) || defined(NBDT_PP_NO_PERSIST) || defined(NBDT_PP_NO_PAD) ||                    \
      defined(NBDT_HALO_NO_ACCUMULATE) || defined(NBDT_DW_TARGET) || defined(NBDT_DW_U) || defined(NBDT_HEAD_SPB) ||    \
-     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) || defined(NBDT_NO_XCD_CONTIGUOUS) || defined(NBDT_CUS_IN_FLIGHT) || defined(NBDT_NT_MIN_MB) ||                      \
+     defined(NBDT_EPI_TIMING) || defined(NBDT_EPI_STATS_ATOMICS) || defined(NBDT_WGT_NSTAGE) || defined(NBDT_NO_XCD_CONTIGUOUS) || defined(NBDT_CUS_IN_FLIGHT) || defined(NBDT_NT_MIN_MB) || defined(NBDT_PLAIN_STORES) ||                      \
      (defined(NBDT_HEAD_SKIP) && (NBDT_HEAD_SKIP + 0) != 0) || (defined(NBDT_PP_ABLATE) && (NBDT_PP_ABLATE + 0) != 0) || \
      (defined(NBDT_PP_SCHED) && (NBDT_PP_SCHED + 0) != 0) || (defined(NBDT_PP_TIMING) && (NBDT_PP_TIMING + 0) != 0) ||  \
      (defined(NBDT_WPP_TIMING) && (NBDT_WPP_TIMING + 0) != 0) || (defined(NBDT_SEG_TIMING) && (NBDT_SEG_TIMING + 0) != 0) || (defined(NBDT_RULES_TIMING) && (NBDT_RULES_TIMING + 0) != 0))
@@ -268,6 +268,22 @@ __device__ __forceinline__ u32x4_t ld16_stream(const void* p) {
 #define NBDT_NT_MIN_MB 96
 #endif
 inline bool stream_nt(long long tensor_bytes) { return tensor_bytes >= ((long long)NBDT_NT_MIN_MB << 20); }
+
+// 16-byte WRITE-THROUGH store (sc1: the line leaves the XCD's L2 as it is written).  Plain stores leave up to 32 MB dirty in
+// the L2s, and the kernel boundary that follows writes them back before the next kernel starts (MI355X_MICROARCH.md,
+// "boundary": + B / 6 TB/s) -- 3-5 us per launch that a short consumer kernel pays in full.  Nothing the next kernel reads
+// would have hit these lines anyway (another XCD's L2 is not coherent with it).  st16<false> is the plain store (timing A/B).
+template <bool WT = true>
+__device__ __forceinline__ void st16(void* p, const u32x4_t v) {
+#ifdef NBDT_PLAIN_STORES          // timing-only builds: rounds 1-5
+  *(u32x4_t*)p = v;
+#else
+  // (s_nop: a VALU write of the data registers within two wait states of a > 8-byte store corrupts it, and hipcc's hazard
+  //  recogniser does not look inside an asm string -- without it the BatchNorm passes lost 2 % of their stores)
+  if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+  else *(u32x4_t*)p = v;
+#endif
+}
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
 #pragma unroll

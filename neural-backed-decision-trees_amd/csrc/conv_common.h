@@ -254,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[NT][MW], const nbdt:
       }
 #pragma unroll
       for (int it = 0; it < ROW_ITERS; ++it)
-        if (live[it]) *(u32x4_t*)(p.out + offs[it] + ch * 8) = ov[it];
+        if (live[it]) st16(p.out + offs[it] + ch * 8, ov[it]);
       if (STATS == 1) {
 #pragma unroll
         for (int it = 0; it < ROW_ITERS; ++it) {

@@ -539,7 +539,9 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_pp_kernel(nbdt::ConvDmaPa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = f32x4{acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine), "v"(v) : "memory");
+          // (s_nop: wait states between a > 8-byte store issued from an asm string and a VALU write of its data registers --
+          //  the next iteration's copy of the accumulators -- which hipcc's hazard recogniser cannot see; csrc/common.h st16)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(mine), "v"(v) : "memory");
           mine += 64 * NWV;
           asm volatile("" : "+v"(mine));
         }

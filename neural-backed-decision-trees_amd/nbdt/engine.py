@@ -427,10 +427,25 @@ class _Engine:
         """Zero the one dirty buffer of every slot pair (a stream-ordered fill on the caller's stream) so that the next
         slot_pair() call finds (zero, zero).  Called at the top of backward(): a hipGraph of a step bakes the pointers
         in, and without this replay k+1's first call per channel count summed into what replay k's last call left."""
-        for pair in self.__dict__.get("_slot_pairs", {}).values():
-            if pair[2] >= 0:
-                pair[pair[2]].zero_()
-                pair[2] = -1
+        pairs = self.__dict__.get("_slot_pairs", {})
+        if not pairs:
+            return
+        if self.__dict__.get("_slot_arena_pairs") != len(pairs):
+            # (re)pack every pair into ONE zeroed arena, so that a step pays one fill launch for all channel counts instead of
+            # one each (three per WRN-28-10 step: 15 us + their launch gaps between forward and backward).  Only when a new
+            # channel count appeared -- the first backward of a shape; GraphedStep's warm-up steps come before its capture.
+            arena = torch.zeros(sum(2 * p[0].numel() for p in pairs.values()), device=self.device)
+            off = 0
+            for p in pairs.values():
+                n = p[0].numel()
+                p[0], p[1], p[2] = arena[off:off + n], arena[off + n:off + 2 * n], -1
+                off += 2 * n
+            self._slot_arena, self._slot_arena_pairs = arena, len(pairs)
+            return
+        if any(p[2] >= 0 for p in pairs.values()):
+            self._slot_arena.zero_()
+            for p in pairs.values():
+                p[2] = -1
 
     def partials(self, out):
         """Workspace for the conv-epilogue BN partial sums of a padded [B,H+2,W+2,C] output."""

@@ -238,7 +238,7 @@ def ptr(t):
 
 
 def stream_of(t):
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index))      # = torch.cuda.current_stream(t.device).cuda_stream
 
 
 def require_gpu(t, what):

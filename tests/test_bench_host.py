@@ -63,14 +63,15 @@ def test_the_newest_file_wins_and_older_ones_are_fallbacks(bench, tmp_path, monk
     assert why2.endswith(bench.TRAFFIC_FILES[0]) and got2 == got + 40
 
 
-def test_committed_bench_line_is_consistent_with_its_committed_evidence(bench, monkeypatch):
-    """profiles/r05_final_bench_line.json (what `python bench.py` printed on the GPU box) against the files it names:
+@pytest.mark.parametrize("line_file", ["r05_final_bench_line.json", "r06_final_bench_line.json"])
+def test_committed_bench_line_is_consistent_with_its_committed_evidence(bench, monkeypatch, line_file):
+    """profiles/r0N_final_bench_line.json (what `python bench.py` printed on the GPU box) against the files it names:
     the traffic it quotes is what pmc_traffic() derives from the committed PMC file it names for the launches that file
     records (the line of the final evidence run is printed BEFORE that run's own PMC passes, i.e. against the previous
     round's file; the next run quotes the new one), value x ms_per_step = the batch, every `frac` is achieved / peak, the
     measured ceilings are ordered achieved < attainable < mfma_stream < peak, every other configuration names an existing
     profile."""
-    with open(os.path.join(ROOT, "profiles", "r05_final_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", line_file)) as f:
         line = json.load(f)
     named = line["roofline"]["traffic_source"].split("/", 1)[1]
     with open(os.path.join(ROOT, "profiles", named)) as f:
@@ -89,6 +90,10 @@ def test_committed_bench_line_is_consistent_with_its_committed_evidence(bench, m
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
     assert line["agreement"]["within_tolerance"] and line["agreement"]["tolerance"] == bench.LOGIT_TOLERANCE
     assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    if "roofline_rules" in line:       # round 6: the fused head's achieved GB/s follows from its bytes and microseconds
+        rr = line["roofline_rules"]
+        assert abs(rr["achieved"] - rr["algorithmic_bytes"] / (rr["us_per_step"] * 1e-6) / 1e9) < 0.02 * rr["achieved"] + 0.01
+        assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-4
     for o in line["other_configs"]:
         assert os.path.exists(os.path.join(ROOT, o["profile"])), o["profile"]
         assert abs(o["frac"] - o["achieved"] / o["peak"]) < 1e-3

@@ -237,8 +237,11 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 def stream_of(t):
-    return c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index))      # = torch.cuda.current_stream(t.device).cuda_stream
+    return c_void_p(_raw_stream(t.device.index))      # = torch.cuda.current_stream(t.device).cuda_stream, without the Stream object
 
 
 def require_gpu(t, what):

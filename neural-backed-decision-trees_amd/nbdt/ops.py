@@ -84,7 +84,15 @@ def stream_ptr(device):
     if idx is None:
         d = torch.device(device)
         idx = _DEV_INDEX[device] = d.index if d.index is not None else torch.cuda.current_device()
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+    return ctypes.c_void_p(_raw_stream(idx))
+
+
+def _raw_stream_public(idx):
+    return torch.cuda.current_stream(idx).cuda_stream
+
+
+# (a private binding: present in every torch this repo has met, but do not depend on it)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", _raw_stream_public)
 
 
 def _fill(desc_arr, values):

@@ -322,9 +322,16 @@ def other_configs(dev, budget_s=0.6):
                      gflop_img=GFLOP_RESNET18_64 / 3, profile="profiles/r06_c4inf_kernel_stats_one_stream.txt",
                      mode="inference: eval-mode backbone + hard decision rules"))
     del eng
+    eng = EfficientNetEngine(1000, device=dev)
     out.append(train_case("C5 EfficientNet-B0 + SoftTreeSupLoss, Imagenet1000 induced hierarchy (1000 leaves), 224x224",
-                          EfficientNetEngine(1000, device=dev), "Imagenet1000", "induced-efficientnet_b7b", 128, 224,
+                          eng, "Imagenet1000", "induced-efficientnet_b7b", 128, 224,
                           1000, 1.0, algorithmic_bytes=True, profile="profiles/r06_c5_kernel_stats_one_stream.txt"))
+    out.append(train_case("C5 EfficientNet-B0 + SoftTreeSupLoss, Imagenet1000 induced hierarchy (1000 leaves), 224x224, 512 "
+                          "images per GPU (BASELINE.json leaves the batch open; at 128 images the 16 units' ~470 launches "
+                          "average 21 us and ~160 of them are 4-5 us folds)",
+                          eng, "Imagenet1000", "induced-efficientnet_b7b", 512, 224,
+                          1000, 1.0, algorithmic_bytes=True, profile="profiles/r06_c5_kernel_stats_one_stream.txt"))
+    del eng
     return out
 
 

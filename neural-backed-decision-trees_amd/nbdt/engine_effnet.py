@@ -377,6 +377,10 @@ class EfficientNetEngine(_Engine):
                 # dL/dgate AND what bn2's backward sums are linear in, in one pass over (gd, d_raw): the reduction pass
                 # of bn_act_bwd (a second read of both tensors) becomes a [B, C]-sized fold once gpool exists
                 sums = self._zeroed(f"se_sums{tag}", (5, B, mid))     # zero on entry, re-zeroed by its last reader
+                dirty = self.__dict__.setdefault("_se_sums_dirty", set())
+                if id(sums) in dirty:        # a backward that stopped between the two calls (an exception, an interrupt) left
+                    sums.zero_()             # its sums behind: never accumulate on top of them
+                dirty.add(id(sums))
                 ops.bn_act_se_sums(gd, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, sums, act=ACT)
                 dgate = sums[0]
             else:
@@ -391,6 +395,7 @@ class EfficientNetEngine(_Engine):
             if one_pass:
                 ops.bn_act_se_bwd_apply(gd, gate, gpool, sums, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, bn.dsum,
                                         st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT)
+                dirty.discard(id(sums))
             else:
                 ops.bn_act_bwd(gd, d_raw, bn.mean, bn.rstd, bn.gamma, bn.beta, self.scratch(bn.C), bn.dsum,
                                st.g(bn.name + ".weight"), st.g(bn.name + ".bias"), gd, act=ACT, gate=gate, gpool=gpool)

@@ -549,3 +549,45 @@ def test_depthwise_data_gradient_with_fused_batchnorm_backward_sums(B, H, W, C, 
             assert float(scratch.abs().max()) == 0.0          # slots left zeroed for the next user
         finally:
             ops.set_deterministic(False)
+
+
+def test_an_interrupted_backward_does_not_poison_the_next_steps_se_sums():
+    """The one-pass SE backward accumulates into a buffer that is zero on entry and re-zeroed by its last reader.  A backward
+    that stops between the two calls leaves it dirty: the engine notices (host-side flag) and zeroes it before the next use,
+    so the next step's gradients equal those of an engine that was never interrupted."""
+    crit = SoftTreeSupLoss(dataset="Imagenet1000", criterion=nn.CrossEntropyLoss(), hierarchy="induced-efficientnet_b7b")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    y = torch.randint(0, 1000, (4,), generator=g).to(DEV)
+    clean = EfficientNetEngine(num_classes=1000, dropout_rate=0.0, device=DEV, seed=3)
+    hurt = EfficientNetEngine(num_classes=1000, dropout_rate=0.0, device=DEV, seed=3)
+    real = ops.bn_act_se_bwd_apply
+    calls = {"n": 0}
+
+    def failing(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise RuntimeError("interrupted")
+        return real(*a, **k)
+
+    ops.bn_act_se_bwd_apply = failing
+    try:
+        hurt.zero_grad()
+        z = hurt.forward(x, training=True)
+        _, gz = crit.loss_and_grad(z, y)
+        with pytest.raises(RuntimeError, match="interrupted"):
+            hurt.backward(gz)
+    finally:
+        ops.bn_act_se_bwd_apply = real
+    torch.cuda.synchronize()
+    hurt.load_state_dict(clean.state_dict())          # same weights and running statistics again
+    outs = []
+    for eng in (clean, hurt):
+        eng.zero_grad()
+        z = eng.forward(x, training=True)
+        _, gz = crit.loss_and_grad(z, y)
+        eng.backward(gz)
+        torch.cuda.synchronize()
+        outs.append(eng.store.grad.clone())
+    rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
+    assert rel < 1e-4, rel           # (fp32 atomics: summation order differs run to run, nothing more)

@@ -590,4 +590,6 @@ def test_an_interrupted_backward_does_not_poison_the_next_steps_se_sums():
         torch.cuda.synchronize()
         outs.append(eng.store.grad.clone())
     rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
-    assert rel < 1e-4, rel           # (fp32 atomics: summation order differs run to run, nothing more)
+    # fp32 atomics: the summation order differs run to run, and a sum that lands on the other side of a bf16 rounding moves
+    # the gradients behind it by an ulp -- 1e-5 ... 1e-3 between two clean engines; the poisoned sums gave 0.31
+    assert rel < 2e-2, rel
